@@ -1,0 +1,186 @@
+"""The numpy oracle against the golden vectors produced by the reference (CPU only)."""
+import numpy as np
+import pytest
+
+from conftest import load_golden, split_prefixed
+from oracle import transformer_np as O
+
+RTOL = 2e-5
+
+
+def close(a, b, rtol=RTOL, atol=2e-6):
+    """max|a-b| <= rtol * max|b| + atol.  The atol floor is for quantities that are zero in
+    exact arithmetic (e.g. the key-bias gradient: softmax is shift invariant)."""
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    err = np.abs(a - b).max()
+    bound = rtol * np.abs(b).max() + atol
+    assert err <= bound, f"max abs err {err:.3e} > {bound:.3e}"
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_attention(dtype):
+    g = load_golden("attention")
+    for tag in ("keypad", "causal", "cross"):
+        q, k, v = (g[f"{tag}_{n}"].astype(dtype) for n in "qkv")
+        temp = np.power(q.shape[-1], 0.5)
+        out, p = O.sdpa_fwd(q, k, v, g[f"{tag}_mask"], temp)
+        close(out, g[f"{tag}_out"])
+        close(p, g[f"{tag}_attn"])
+        dq, dk, dv = O.sdpa_bwd(q, k, v, p, g[f"{tag}_dout"].astype(dtype), temp)
+        close(dq, g[f"{tag}_dq"]); close(dk, g[f"{tag}_dk"]); close(dv, g[f"{tag}_dv"])
+
+
+def test_sinusoid():
+    g = load_golden("sinusoid")
+    np.testing.assert_array_equal(O.sinusoid_table(20, 32, 0), g["t_20_32"])
+    np.testing.assert_array_equal(O.sinusoid_table(7, 6, 0), g["t_7_6"])
+    np.testing.assert_array_equal(O.sinusoid_table(5, 8), g["t_5_8_nopad"])
+
+
+@pytest.mark.parametrize("tag", ["mha_self", "mha_cross"])
+def test_mha(tag):
+    g = load_golden(tag)
+    w, gw = split_prefixed(g, "w:"), split_prefixed(g, "g:")
+    n_head, d_model, dk, dv = g["cfg"].tolist()
+    out, p, cache = O.mha_fwd(w, "", g["x"], g["mem"], g["mask"], n_head, dk, dv)
+    close(out, g["out"]); close(p, g["attn"])
+    grads = {}
+    dq, dkv = O.mha_bwd(w, "", g["dout"], cache, n_head, dk, dv, grads)
+    if tag == "mha_self":
+        close(dq + dkv, g["dx"])
+    else:
+        close(dq, g["dx"]); close(dkv, g["dmem"])
+    for k in gw:
+        close(grads[k], gw[k])
+
+
+def test_ffn():
+    g = load_golden("ffn")
+    w, gw = split_prefixed(g, "w:"), split_prefixed(g, "g:")
+    out, cache = O.ffn_fwd(w, "", g["x"])
+    close(out, g["out"])
+    grads = {}
+    close(O.ffn_bwd(w, "", g["dout"], cache, grads), g["dx"])
+    for k in gw:
+        close(grads[k], gw[k])
+
+
+def test_layers():
+    g = load_golden("enc_layer")
+    w, gw = split_prefixed(g, "w:"), split_prefixed(g, "g:")
+    n_head, d_model, dk, dv, d_inner = g["cfg"].tolist()
+    out, p, cache = O.enc_layer_fwd(w, "", g["x"], g["keypad"], (n_head, dk, dv))
+    close(out, g["out"]); close(p, g["attn"])
+    assert (out[g["keypad"]] == 0).all()
+    grads = {}
+    close(O.enc_layer_bwd(w, "", g["dout"], cache, (n_head, dk, dv), grads), g["dx"])
+    for k in gw:
+        close(grads[k], gw[k])
+
+    g = load_golden("dec_layer")
+    w, gw = split_prefixed(g, "w:"), split_prefixed(g, "g:")
+    out, p1, p2, cache = O.dec_layer_fwd(w, "", g["x"], g["mem"], g["keypad"], g["src_keypad"], (n_head, dk, dv))
+    close(out, g["out"]); close(p1, g["slf_attn"]); close(p2, g["enc_attn"])
+    grads = {}
+    dx, dmem = O.dec_layer_bwd(w, "", g["dout"], cache, (n_head, dk, dv), grads)
+    close(dx, g["dx"]); close(dmem, g["dmem"])
+    for k in gw:
+        close(grads[k], gw[k])
+
+
+def tiny_cfg(tied):
+    return O.Config(n_layers=2, n_head=4, d_k=8, d_v=8, d_model=32, d_inner=64, tied_proj=tied)
+
+
+@pytest.mark.parametrize("tag", ["transformer_untied", "transformer_tied"])
+def test_transformer(tag):
+    g = load_golden(tag)
+    tied = bool(g["tied"])
+    w = split_prefixed(g, "w:")
+    cfg = tiny_cfg(tied)
+    assert cfg.x_logit_scale == float(g["x_logit_scale"])
+    logits, cache = O.transformer_fwd(w, cfg, g["src_seq"], g["src_pos"], g["tgt_seq"], g["tgt_pos"])
+    close(logits, g["logits"])
+    gold = g["tgt_seq"][:, 1:].reshape(-1)
+    for s, smoothing in (("ls", True), ("ce", False)):
+        loss, dpred, nc = O.ls_xent(logits.reshape(-1, logits.shape[-1]), gold, smoothing)
+        close(loss, g[f"loss_{s}"])
+        assert nc == int(g[f"ncorrect_{s}"])
+        grads = O.tie_grads(O.transformer_bwd(w, cfg, dpred.reshape(logits.shape), cache), tied, tied)
+        gw = split_prefixed(g, f"g_{s}:")
+        assert set(gw) <= set(grads)
+        for k in gw:
+            close(grads[k], gw[k], rtol=5e-5)
+
+
+def test_loss():
+    g = load_golden("loss")
+    for s, smoothing in (("ls", True), ("ce", False)):
+        loss, dpred, nc = O.ls_xent(g["pred"], g["gold"], smoothing)
+        close(loss, g[f"loss_{s}"]); close(dpred, g[f"dpred_{s}"])
+        assert nc == int(g[f"ncorrect_{s}"])
+
+
+def test_optim():
+    g = load_golden("optim")
+    d_model, warm = int(g["d_model"]), int(g["n_warmup"])
+    p1, p2 = g["p1_0"].copy(), g["p2_0"].copy()
+    st = [np.zeros_like(p1), np.zeros_like(p1), np.zeros_like(p2), np.zeros_like(p2)]
+    for step in range(1, 7):
+        lr = O.noam_lr(step, d_model, warm)
+        assert abs(lr - g["lrs"][step - 1]) <= 1e-12 * lr
+        O.adam_step(p1, g[f"g1_{step}"], st[0], st[1], step, np.float32(lr))
+        O.adam_step(p2, g[f"g2_{step}"], st[2], st[3], step, np.float32(lr))
+        close(p1, g[f"p1_{step}"], rtol=1e-6); close(p2, g[f"p2_{step}"], rtol=1e-6)
+
+
+def test_train4():
+    g = load_golden("train4")
+    w = {k: v.copy() for k, v in split_prefixed(g, "w0:").items()}
+    cfg = tiny_cfg(False)
+    trainable = [k for k in w if "position_enc" not in k]
+    m = {k: np.zeros_like(w[k]) for k in trainable}
+    v = {k: np.zeros_like(w[k]) for k in trainable}
+    for step in range(4):
+        b = [g[f"{n}_{step}"] for n in ("src_seq", "src_pos", "tgt_seq", "tgt_pos")]
+        logits, cache = O.transformer_fwd(w, cfg, *b)
+        loss, dpred, nc = O.ls_xent(logits.reshape(-1, logits.shape[-1]), b[2][:, 1:].reshape(-1), True)
+        assert abs(loss - g["losses"][step]) <= 2e-5 * abs(g["losses"][step])
+        assert nc == g["ncorrect"][step]
+        grads = O.transformer_bwd(w, cfg, dpred.reshape(logits.shape), cache)
+        lr = np.float32(O.noam_lr(step + 1, cfg.d_model, int(g["n_warmup"])))
+        for k in trainable:
+            O.adam_step(w[k], grads[k], m[k], v[k], step + 1, lr)
+    w4 = split_prefixed(g, "w4:")
+    for k in trainable:
+        if k.endswith("w_ks.bias"):
+            # The key bias shifts every score of a row equally, so its true gradient is 0 and
+            # it never affects an output.  Adam (eps=1e-9) turns the fp32 rounding noise in
+            # that gradient into +-lr steps, so its value is not reproducible across
+            # summation orders -- not even between two runs of the reference.
+            continue
+        close(w[k], w4[k], rtol=2e-4)
+
+
+def test_beam():
+    g = load_golden("beam")
+    w = split_prefixed(g, "w:")
+    cfg = tiny_cfg(False)
+    enc, _, _ = O.encoder_fwd(w, cfg, g["src_seq"], g["src_pos"])
+    n = g["src_seq"].shape[0]
+    dec, _, _, _ = O.decoder_fwd(w, cfg, np.full((n, 1), O.SOS), np.ones((n, 1), dtype=np.int64), g["src_seq"], enc)
+    close(O.log_softmax(dec[:, -1] @ w["generator.weight"].T), g["step1_logp"])
+    for bm, nb in ((1, 1), (3, 2), (5, 1), (5, 3)):
+        hyps, scores = O.translate_batch(w, cfg, g["src_seq"], g["src_pos"], bm, nb, int(g["len_max_seq"]))
+        H, Ln, S = g[f"hyp_b{bm}_n{nb}"], g[f"len_b{bm}_n{nb}"], g[f"score_b{bm}_n{nb}"]
+        for i in range(n):
+            for j in range(nb):
+                assert hyps[i][j] == H[i, j, : Ln[i, j]].tolist(), (bm, nb, i, j)
+            np.testing.assert_allclose(scores[i], S[i], rtol=1e-4, atol=1e-5)
+
+
+def test_collate():
+    seq, pos = O.collate([[2, 7, 8, 3], [2, 9, 3]])
+    assert seq.tolist() == [[2, 7, 8, 3], [2, 9, 3, 0]]
+    assert pos.tolist() == [[1, 2, 3, 4], [1, 2, 3, 0]]
