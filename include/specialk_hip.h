@@ -1,0 +1,201 @@
+/*
+ * specialk_hip.h — C ABI of libspecialk_hip.so, the MI355X (gfx950) kernels behind the
+ * Transformer encoder-decoder hot path of thien/specialk.
+ *
+ * The reference has no FFI: its "operator layer" is stock PyTorch (torch.bmm, nn.Linear,
+ * nn.LayerNorm, F.log_softmax, optim.Adam ...) called from the files under base/lib/transformer/.  Each
+ * entry point below therefore cites the reference call site(s) whose arithmetic it replaces
+ * (paths relative to the reference's base/ directory).
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative SK_ERR_* otherwise;
+ *     skhip_last_error() returns a thread-local message for the last failure;
+ *   - all pointers are DEVICE pointers unless named host_*; the caller owns every buffer;
+ *   - nothing here allocates, frees or synchronises; work is enqueued on `stream`
+ *     (a hipStream_t passed as void*; NULL = the default stream);
+ *   - matrices are row-major with explicit leading dimensions in ELEMENTS;
+ *   - `dtype` is SK_F32 or SK_BF16 and names the storage type of activations / weights;
+ *     accumulation, softmax and LayerNorm statistics are always fp32.
+ */
+#ifndef SPECIALK_HIP_H
+#define SPECIALK_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SK_F32 0
+#define SK_BF16 1
+
+#define SK_OK 0
+#define SK_ERR_ARG (-1)     /* bad shape / alignment / unsupported combination */
+#define SK_ERR_LAUNCH (-2)  /* hipLaunch / runtime error */
+#define SK_ERR_WORKSPACE (-3)
+
+/* GEMM operand layouts: C[M,N] = alpha * op(A)[M,K] * op(B)[K,N] (+ epilogue)           */
+#define SK_GEMM_NT 0 /* A stored [M][K], B stored [N][K]   (nn.Linear forward)            */
+#define SK_GEMM_NN 1 /* A stored [M][K], B stored [K][N]   (input gradient)               */
+#define SK_GEMM_TN 2 /* A stored [K][M], B stored [K][N]   (weight gradient)              */
+
+/* GEMM epilogue flags (bit-or) */
+#define SK_EPI_BIAS 1      /* + bias[n]                                                   */
+#define SK_EPI_RELU 2      /* max(., 0)                                                   */
+#define SK_EPI_RELU_MASK 4 /* multiply by (aux[m][n] > 0): backward of ReLU               */
+#define SK_EPI_ACCUM 8     /* C = result + C_old                                          */
+
+const char* skhip_version(void);
+const char* skhip_last_error(void);
+
+/* ---- init ---------------------------------------------------------------------------
+ * Optional: queries the current device once (CU count) so that launch heuristics do not
+ * touch the runtime on the hot path.  Every entry point calls it lazily.                */
+int skhip_init(void);
+
+/* ---- GEMM ---------------------------------------------------------------------------
+ * Replaces: nn.Linear w_qs/w_ks/w_vs/fc (lib/transformer/SubLayers.py:46-48,62), the
+ * Conv1d(k=1) pair of the FFN (SubLayers.py:73-74,81), the generator projection
+ * (lib/transformer/Models.py:252,278) and their autograd backward.
+ * in_dtype: storage of A and B; out_dtype: storage of C (bf16 inputs may write fp32, used
+ * for weight gradients).  bias is always fp32 [N] (the master parameter).  aux (RELU_MASK)
+ * has C's shape, ldc and in_dtype.
+ * workspace: optional fp32 scratch for deterministic split-K (may be NULL: no split).     */
+int skhip_gemm(int layout, const void* A, const void* B, void* C, const void* bias, const void* aux,
+               int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc,
+               float alpha, int epilogue, int in_dtype, int out_dtype,
+               void* workspace, int64_t workspace_bytes, void* stream);
+
+/* Column sums: out[n] (+)= sum_m X[m][n]  (bias gradients).  out is fp32.                */
+int skhip_colsum(const void* X, float* out, int64_t M, int64_t N, int64_t ldx, int accumulate,
+                 int dtype, void* stream);
+
+/* ---- attention ----------------------------------------------------------------------
+ * Replaces ScaledDotProductAttention.forward (lib/transformer/Modules.py:17-28) together
+ * with the head split / merge copies and the h-fold mask repeat of MultiHeadAttention
+ * (lib/transformer/SubLayers.py:50-60), and their backward.
+ * Q is read as Q[b][i][head*dk + c] = Q[(b*Lq + i)*ldq + head*dk + c]; same for K, V, O
+ * (so a fused [q|k|v] projection output is consumed in place by pointing Q, K, V into it).
+ * Masking (lib/transformer/Models.py:49-69,173-177): key j of batch b is masked when
+ * key_pad[b*Lk + j] != 0, and, if causal, when j > i.  dense_mask (optional, uint8
+ * [B][Lq][Lk], nonzero = masked) is OR-ed in for callers that hold an arbitrary mask.
+ * Fully masked rows produce NaN like the reference's softmax.
+ * p_drop > 0 applies dropout to the probabilities (Modules.py:25) with a counter-based
+ * generator keyed by (seed, b, head, i, j); backward regenerates the same mask.
+ * LSE [B][h][Lq] fp32 receives the row log-sum-exp (of the scaled, masked scores), which
+ * backward needs.  P_out (optional, in `dtype`, [h][B][Lq][Lk] head-major like the
+ * reference's returned attn, after dropout) is only written when non-NULL.              */
+int skhip_attn_fwd(const void* Q, const void* K, const void* V, void* O, float* LSE, void* P_out,
+                   const uint8_t* key_pad, const uint8_t* dense_mask,
+                   int B, int n_head, int Lq, int Lk, int dk, int dv,
+                   int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
+                   float scale, int causal, float p_drop, uint64_t seed,
+                   int dtype, void* stream);
+
+/* dQ/dK/dV are written (not accumulated) with the same addressing as Q/K/V.
+ * delta_ws: fp32 scratch [B][h][Lq].                                                     */
+int skhip_attn_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO,
+                   const float* LSE, void* dQ, void* dK, void* dV, float* delta_ws,
+                   const uint8_t* key_pad, const uint8_t* dense_mask,
+                   int B, int n_head, int Lq, int Lk, int dk, int dv,
+                   int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
+                   int64_t lddq, int64_t lddk, int64_t lddv,
+                   float scale, int causal, float p_drop, uint64_t seed,
+                   int dtype, void* stream);
+
+/* ---- residual + dropout + LayerNorm + pad-row zeroing --------------------------------
+ * y = LayerNorm(res + dropout_p(x)) * gamma + beta, rows with row_pad != 0 set to 0.
+ * Replaces `self.layer_norm(self.dropout(out) + residual)` (SubLayers.py:62-63,83-84) and
+ * the `*= non_pad_mask` that follows every sublayer (lib/transformer/Layers.py:22-58).
+ * gamma/beta fp32; mean/rstd fp32 [T] saved for backward; row_pad may be NULL.            */
+int skhip_add_ln_fwd(const void* x, const void* res, const float* gamma, const float* beta,
+                     const uint8_t* row_pad, void* y, float* mean, float* rstd,
+                     int64_t T, int d, float eps, float p_drop, uint64_t seed,
+                     int dtype, void* stream);
+
+/* dx = grad wrt x (through dropout), dres = grad wrt res (may alias dx when p_drop == 0).
+ * dgamma/dbeta fp32 [d] are ACCUMULATED when accumulate != 0, else overwritten.
+ * partial_ws: fp32 scratch of at least skhip_add_ln_bwd_ws_floats(d) floats.              */
+int64_t skhip_add_ln_bwd_ws_floats(int d);
+int skhip_add_ln_bwd(const void* dy, const void* x, const void* res, const float* gamma,
+                     const uint8_t* row_pad, const float* mean, const float* rstd,
+                     void* dx, void* dres, float* dgamma, float* dbeta, float* partial_ws,
+                     int64_t T, int d, float p_drop, uint64_t seed, int accumulate,
+                     int dtype, void* stream);
+
+/* ---- embeddings ----------------------------------------------------------------------
+ * out[t] = word_emb[seq[t]] + pos_table[pos[t]]   (lib/transformer/Models.py:117-118,
+ * 181-182; no sqrt(d) scaling).  Tables are fp32 (master weights); out is `dtype`.        */
+int skhip_embed_fwd(const int64_t* seq, const int64_t* pos, const float* word_emb,
+                    const float* pos_table, void* out, int64_t T, int d, int64_t n_vocab,
+                    int64_t n_pos, int dtype, void* stream);
+/* dword_emb[seq[t]] += dout[t] for seq[t] != pad_id (nn.Embedding(padding_idx=PAD));
+ * dword_emb fp32, caller zeroes it (or lets several calls accumulate for tied tables).    */
+int skhip_embed_bwd(const int64_t* seq, const void* dout, float* dword_emb, int64_t T, int d,
+                    int64_t n_vocab, int64_t pad_id, int dtype, void* stream);
+
+/* ---- label-smoothed softmax cross-entropy, forward + backward + accuracy -------------
+ * Replaces calculate_loss / performance (lib/TransformerModel.py:340-375).
+ * logits [T][V] (ld = ldl) are multiplied by `logit_scale` first (x_logit_scale,
+ * lib/transformer/Models.py:262-264,278).  smoothing_eps = 0 gives plain cross_entropy with
+ * ignore_index = pad_id, reduction = "sum".
+ * out_stats (double[3], caller zeroes): [0] += loss sum, [1] += n_correct, [2] += n_non_pad.
+ * dlogits (may alias logits; may be NULL for evaluation) receives
+ * grad_scale * logit_scale * (softmax - q) on non-pad rows and 0 on pad rows.            */
+int skhip_xent_fwd_bwd(const void* logits, const int64_t* gold, void* dlogits, double* out_stats,
+                       int64_t T, int64_t V, int64_t ldl, float logit_scale, float smoothing_eps,
+                       int64_t pad_id, float grad_scale, int dtype, void* stream);
+
+/* ---- Adam ---------------------------------------------------------------------------
+ * One launch over n tensors: torch.optim.Adam(betas, eps, no weight decay) as configured in
+ * lib/TransformerModel.py:159-165, with the learning rate of lib/transformer/Optim.py:24-36
+ * computed by the caller.  The five tables are DEVICE arrays of n entries: fp32 param,
+ * fp32 grad, fp32 exp_avg, fp32 exp_avg_sq pointers, element counts; bf16_copy[i] (table may
+ * be NULL, entries may be 0) receives the updated parameter rounded to bf16.
+ * grad_scale multiplies every gradient first (1.0 for the reference's behaviour).        */
+int skhip_adam_multi(const uint64_t* param_ptrs, const uint64_t* grad_ptrs, const uint64_t* m_ptrs,
+                     const uint64_t* v_ptrs, const uint64_t* bf16_copy_ptrs, const int64_t* counts,
+                     int n, int64_t max_count, float lr, float beta1, float beta2, float eps,
+                     int step, float grad_scale, void* stream);
+
+/* dst = (bf16) src for n tensors (same table convention), used once after loading weights. */
+int skhip_cast_multi(const uint64_t* src_f32_ptrs, const uint64_t* dst_bf16_ptrs,
+                     const int64_t* counts, int n, int64_t max_count, void* stream);
+/* dst[i] = convert(src[i]); dtypes SK_F32 / SK_BF16.                                      */
+int skhip_convert(const void* src, void* dst, int64_t n, int src_dtype, int dst_dtype, void* stream);
+
+/* ---- beam-search decode ---------------------------------------------------------------
+ * Replace Translator.translate_batch's per-step work (lib/transformer/Translator.py:103-168)
+ * and Beam.advance (lib/transformer/Beam.py:46-79).                                        */
+
+/* Single-query attention over a KV cache (incremental replacement for re-running the
+ * decoder on the whole prefix, Translator.py:130-140).  q [R][h*dk]; K/V cache
+ * [R][Lmax][h*dk|h*dv] of which the first kv_len[r] (or `len` if kv_len NULL) entries are
+ * valid; key_pad optional [R][Lmax].  out [R][h*dv].                                       */
+int skhip_decode_attn(const void* q, const void* Kc, const void* Vc, void* out,
+                      const int32_t* kv_len, const uint8_t* key_pad, int R, int n_head, int len,
+                      int Lmax, int dk, int dv, int64_t ldq, int64_t ldo, float scale,
+                      int dtype, void* stream);
+
+/* log_softmax over V + beam expansion + top-`bm` per sentence.
+ * logits [n_sent*bm][V] fp32 (ld = V).  scores_in [n_sent][bm] fp32.
+ * first_step != 0: only beam 0 of each sentence is considered (Beam.py:51-54).
+ * Outputs per sentence, sorted by descending score, ties to the lower flat index:
+ * scores_out [n_sent][bm], prev_out [n_sent][bm] (source beam = flat_id / V),
+ * tok_out [n_sent][bm] (flat_id - prev*V).  ws: fp32/int scratch of
+ * skhip_beam_topk_ws_bytes(n_sent, bm, V) bytes.                                           */
+int64_t skhip_beam_topk_ws_bytes(int n_sent, int bm, int64_t V);
+int skhip_beam_topk(const float* logits, const float* scores_in, float* scores_out,
+                    int32_t* prev_out, int32_t* tok_out, void* ws, int n_sent, int bm, int64_t V,
+                    int first_step, void* stream);
+
+/* Reorder a cache after a beam step: dst[r] = src[src_row[r]] for rows of `row_elems`
+ * elements (replaces re-building dec_seq from back-pointers every step, Beam.py:90-110,
+ * and the index_select compaction, Translator.py:65-101).                                  */
+int skhip_gather_rows(const void* src, void* dst, const int32_t* src_row, int64_t n_rows,
+                      int64_t row_elems, int64_t src_stride, int64_t dst_stride, int dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPECIALK_HIP_H */

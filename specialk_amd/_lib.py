@@ -1,0 +1,274 @@
+"""ctypes binding of libspecialk_hip.so (the C ABI declared in include/specialk_hip.h).
+
+PyTorch is only the host here: it owns device memory and streams.  Every function below
+passes raw device pointers, sizes and the current HIP stream to the library.  There is no
+CPU or torch fallback: if the shared library is missing, or a call is made with non-GPU
+tensors, this module raises.
+"""
+import ctypes
+import os
+
+import torch
+
+SK_F32, SK_BF16 = 0, 1
+GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
+EPI_BIAS, EPI_RELU, EPI_RELU_MASK, EPI_ACCUM = 1, 2, 4, 8
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libspecialk_hip.so")
+
+# every symbol include/specialk_hip.h declares
+EXPORTS = [
+    "skhip_version", "skhip_last_error", "skhip_init", "skhip_gemm", "skhip_colsum", "skhip_attn_fwd",
+    "skhip_attn_bwd", "skhip_add_ln_fwd", "skhip_add_ln_bwd_ws_floats", "skhip_add_ln_bwd", "skhip_embed_fwd",
+    "skhip_embed_bwd", "skhip_xent_fwd_bwd", "skhip_adam_multi", "skhip_cast_multi", "skhip_convert",
+    "skhip_decode_attn", "skhip_beam_topk_ws_bytes", "skhip_beam_topk", "skhip_gather_rows",
+]
+
+_lib = None
+c_i64, c_int, c_f32, c_u64, c_p = ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_uint64, ctypes.c_void_p
+
+
+def load():
+    """Load the library once; fail loudly when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: build it with `make -C specialk_amd/csrc` (or __graft_entry__.build()). "
+            "specialk_amd has no CPU fallback."
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.skhip_version.restype = ctypes.c_char_p
+    lib.skhip_last_error.restype = ctypes.c_char_p
+    lib.skhip_add_ln_bwd_ws_floats.restype = c_i64
+    lib.skhip_add_ln_bwd_ws_floats.argtypes = [c_int]
+    lib.skhip_beam_topk_ws_bytes.restype = c_i64
+    lib.skhip_beam_topk_ws_bytes.argtypes = [c_int, c_int, c_i64]
+    lib.skhip_gemm.argtypes = [c_int, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_f32,
+                               c_int, c_int, c_int, c_p, c_i64, c_p]
+    lib.skhip_colsum.argtypes = [c_p, c_p, c_i64, c_i64, c_i64, c_int, c_int, c_p]
+    lib.skhip_attn_fwd.argtypes = [c_p] * 8 + [c_int] * 6 + [c_i64] * 4 + [c_f32, c_int, c_f32, c_u64, c_int, c_p]
+    lib.skhip_attn_bwd.argtypes = [c_p] * 12 + [c_int] * 6 + [c_i64] * 7 + [c_f32, c_int, c_f32, c_u64, c_int, c_p]
+    lib.skhip_add_ln_fwd.argtypes = [c_p] * 8 + [c_i64, c_int, c_f32, c_f32, c_u64, c_int, c_p]
+    lib.skhip_add_ln_bwd.argtypes = [c_p] * 12 + [c_i64, c_int, c_f32, c_u64, c_int, c_int, c_p]
+    lib.skhip_embed_fwd.argtypes = [c_p] * 5 + [c_i64, c_int, c_i64, c_i64, c_int, c_p]
+    lib.skhip_embed_bwd.argtypes = [c_p] * 3 + [c_i64, c_int, c_i64, c_i64, c_int, c_p]
+    lib.skhip_xent_fwd_bwd.argtypes = [c_p] * 4 + [c_i64, c_i64, c_i64, c_f32, c_f32, c_i64, c_f32, c_int, c_p]
+    lib.skhip_adam_multi.argtypes = [c_p] * 6 + [c_int, c_i64, c_f32, c_f32, c_f32, c_f32, c_int, c_f32, c_p]
+    lib.skhip_cast_multi.argtypes = [c_p] * 3 + [c_int, c_i64, c_p]
+    lib.skhip_convert.argtypes = [c_p, c_p, c_i64, c_int, c_int, c_p]
+    lib.skhip_decode_attn.argtypes = [c_p] * 6 + [c_int] * 6 + [c_i64, c_i64, c_f32, c_int, c_p]
+    lib.skhip_beam_topk.argtypes = [c_p] * 6 + [c_int, c_int, c_i64, c_int, c_p]
+    lib.skhip_gather_rows.argtypes = [c_p] * 3 + [c_i64] * 4 + [c_int, c_p]
+    for name in EXPORTS:
+        getattr(lib, name)  # AttributeError here means header and library disagree
+    _lib = lib
+    return lib
+
+
+def version():
+    return load().skhip_version().decode()
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise RuntimeError(f"{what} failed ({rc}): {load().skhip_last_error().decode()}")
+
+
+def dcode(dtype):
+    if dtype == torch.float32:
+        return SK_F32
+    if dtype == torch.bfloat16:
+        return SK_BF16
+    raise TypeError(f"specialk_amd supports float32 and bfloat16 storage, got {dtype}")
+
+
+def _ptr(t):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("specialk_amd kernels need GPU tensors (there is no CPU path)")
+    return t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+_workspaces = {}
+
+
+def workspace(nbytes=64 << 20, device=None):
+    """Persistent scratch per device (split-K slabs, LayerNorm partials, beam candidates)."""
+    device = torch.device("cuda", torch.cuda.current_device()) if device is None else device
+    ws = _workspaces.get(device)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(nbytes, 64 << 20), dtype=torch.uint8, device=device)
+        _workspaces[device] = ws
+    return ws
+
+
+# --------------------------------------------------------------------------- GEMM
+def gemm(layout, A, B, M, N, K, lda, ldb, out=None, ldc=None, bias=None, aux=None, alpha=1.0, epilogue=0,
+         out_dtype=None, split_k=True):
+    """C[M,N] = alpha * op(A) op(B) with the library's epilogues.  A, B, out are 2-D views whose
+    base pointer and leading dimension are given explicitly (so slices of fused buffers work)."""
+    lib = load()
+    out_dtype = A.dtype if out_dtype is None else out_dtype
+    if out is None:
+        out = torch.empty((M, N), dtype=out_dtype, device=A.device)
+        ldc = N
+    if bias is not None:
+        assert bias.dtype == torch.float32
+        epilogue |= EPI_BIAS
+    ws = workspace() if split_k else None
+    rc = lib.skhip_gemm(layout, _ptr(A), _ptr(B), _ptr(out), _ptr(bias), _ptr(aux), M, N, K, lda, ldb, ldc,
+                        float(alpha), epilogue, dcode(A.dtype), dcode(out.dtype), _ptr(ws),
+                        ws.numel() if ws is not None else 0, _stream())
+    _check(rc, "skhip_gemm")
+    return out
+
+
+def colsum(X, M, N, ldx, out=None, accumulate=False):
+    lib = load()
+    if out is None:
+        out = torch.empty(N, dtype=torch.float32, device=X.device)
+    _check(lib.skhip_colsum(_ptr(X), _ptr(out), M, N, ldx, int(accumulate), dcode(X.dtype), _stream()), "skhip_colsum")
+    return out
+
+
+# --------------------------------------------------------------------------- attention
+def attn_fwd(Q, K, V, O, LSE, B, H, Lq, Lk, dk, dv, ldq, ldk, ldv, ldo, scale, key_pad=None, dense_mask=None,
+             causal=False, p_drop=0.0, seed=0, P_out=None):
+    lib = load()
+    rc = lib.skhip_attn_fwd(_ptr(Q), _ptr(K), _ptr(V), _ptr(O), _ptr(LSE), _ptr(P_out), _ptr(key_pad),
+                            _ptr(dense_mask), B, H, Lq, Lk, dk, dv, ldq, ldk, ldv, ldo, float(scale), int(causal),
+                            float(p_drop), int(seed), dcode(Q.dtype), _stream())
+    _check(rc, "skhip_attn_fwd")
+
+
+def attn_bwd(Q, K, V, O, dO, LSE, dQ, dK, dV, delta, B, H, Lq, Lk, dk, dv, ldq, ldk, ldv, ldo, lddq, lddk, lddv,
+             scale, key_pad=None, dense_mask=None, causal=False, p_drop=0.0, seed=0):
+    lib = load()
+    rc = lib.skhip_attn_bwd(_ptr(Q), _ptr(K), _ptr(V), _ptr(O), _ptr(dO), _ptr(LSE), _ptr(dQ), _ptr(dK), _ptr(dV),
+                            _ptr(delta), _ptr(key_pad), _ptr(dense_mask), B, H, Lq, Lk, dk, dv, ldq, ldk, ldv, ldo,
+                            lddq, lddk, lddv, float(scale), int(causal), float(p_drop), int(seed), dcode(Q.dtype),
+                            _stream())
+    _check(rc, "skhip_attn_bwd")
+
+
+# --------------------------------------------------------------------------- add + LayerNorm
+def add_ln_fwd(x, res, gamma, beta, row_pad, eps, p_drop, seed):
+    lib = load()
+    T, d = x.shape
+    y = torch.empty_like(x)
+    mean = torch.empty(T, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(T, dtype=torch.float32, device=x.device)
+    rc = lib.skhip_add_ln_fwd(_ptr(x), _ptr(res), _ptr(gamma), _ptr(beta), _ptr(row_pad), _ptr(y), _ptr(mean),
+                              _ptr(rstd), T, d, float(eps), float(p_drop), int(seed), dcode(x.dtype), _stream())
+    _check(rc, "skhip_add_ln_fwd")
+    return y, mean, rstd
+
+
+def add_ln_bwd(dy, x, res, gamma, row_pad, mean, rstd, p_drop, seed, dgamma=None, dbeta=None, accumulate=False):
+    lib = load()
+    T, d = x.shape
+    dres = torch.empty_like(x)
+    dx = torch.empty_like(x) if p_drop > 0 else dres
+    if dgamma is None:
+        dgamma = torch.empty(d, dtype=torch.float32, device=x.device)
+        dbeta = torch.empty(d, dtype=torch.float32, device=x.device)
+        accumulate = False
+    ws = workspace(int(lib.skhip_add_ln_bwd_ws_floats(d)) * 4)
+    rc = lib.skhip_add_ln_bwd(_ptr(dy), _ptr(x), _ptr(res), _ptr(gamma), _ptr(row_pad), _ptr(mean), _ptr(rstd),
+                              _ptr(dx), _ptr(dres), _ptr(dgamma), _ptr(dbeta), _ptr(ws), T, d, float(p_drop),
+                              int(seed), int(accumulate), dcode(x.dtype), _stream())
+    _check(rc, "skhip_add_ln_bwd")
+    return dx, dres, dgamma, dbeta
+
+
+# --------------------------------------------------------------------------- embeddings
+def embed_fwd(seq, pos, word_emb, pos_table, dtype):
+    lib = load()
+    T = seq.numel()
+    d = word_emb.shape[1]
+    out = torch.empty((T, d), dtype=dtype, device=seq.device)
+    rc = lib.skhip_embed_fwd(_ptr(seq), _ptr(pos), _ptr(word_emb), _ptr(pos_table), _ptr(out), T, d,
+                             word_emb.shape[0], pos_table.shape[0], dcode(dtype), _stream())
+    _check(rc, "skhip_embed_fwd")
+    return out
+
+
+def embed_bwd(seq, dout, dword_emb, pad_id):
+    lib = load()
+    T = seq.numel()
+    d = dword_emb.shape[1]
+    rc = lib.skhip_embed_bwd(_ptr(seq), _ptr(dout), _ptr(dword_emb), T, d, dword_emb.shape[0], pad_id,
+                             dcode(dout.dtype), _stream())
+    _check(rc, "skhip_embed_bwd")
+
+
+# --------------------------------------------------------------------------- loss
+def xent_fwd_bwd(logits, gold, dlogits, stats, logit_scale, smoothing_eps, pad_id, grad_scale=1.0):
+    """logits (T,V) contiguous; stats float64[3] on device, accumulated into."""
+    lib = load()
+    T, V = logits.shape
+    rc = lib.skhip_xent_fwd_bwd(_ptr(logits), _ptr(gold), _ptr(dlogits), _ptr(stats), T, V, logits.stride(0),
+                                float(logit_scale), float(smoothing_eps), pad_id, float(grad_scale),
+                                dcode(logits.dtype), _stream())
+    _check(rc, "skhip_xent_fwd_bwd")
+
+
+# --------------------------------------------------------------------------- optimiser
+def adam_multi(tables, n, max_count, lr, beta1, beta2, eps, step, grad_scale=1.0):
+    """tables: dict of device int64 tensors 'p','g','m','v','b'(or None),'n'."""
+    lib = load()
+    rc = lib.skhip_adam_multi(_ptr(tables["p"]), _ptr(tables["g"]), _ptr(tables["m"]), _ptr(tables["v"]),
+                              _ptr(tables.get("b")), _ptr(tables["n"]), n, max_count, float(lr), float(beta1),
+                              float(beta2), float(eps), int(step), float(grad_scale), _stream())
+    _check(rc, "skhip_adam_multi")
+
+
+def cast_multi(src_table, dst_table, counts, n, max_count):
+    lib = load()
+    _check(lib.skhip_cast_multi(_ptr(src_table), _ptr(dst_table), _ptr(counts), n, max_count, _stream()),
+           "skhip_cast_multi")
+
+
+def convert(src, dst):
+    lib = load()
+    assert src.numel() == dst.numel() and src.is_contiguous() and dst.is_contiguous()
+    _check(lib.skhip_convert(_ptr(src), _ptr(dst), src.numel(), dcode(src.dtype), dcode(dst.dtype), _stream()),
+           "skhip_convert")
+    return dst
+
+
+# --------------------------------------------------------------------------- decode
+def decode_attn(q, Kc, Vc, out, R, H, length, Lmax, dk, dv, ldq, ldo, scale, kv_len=None, key_pad=None):
+    lib = load()
+    rc = lib.skhip_decode_attn(_ptr(q), _ptr(Kc), _ptr(Vc), _ptr(out), _ptr(kv_len), _ptr(key_pad), R, H, length,
+                               Lmax, dk, dv, ldq, ldo, float(scale), dcode(q.dtype), _stream())
+    _check(rc, "skhip_decode_attn")
+
+
+def beam_topk(logits, scores_in, n_sent, bm, first_step):
+    lib = load()
+    V = logits.shape[-1]
+    dev = logits.device
+    scores_out = torch.empty((n_sent, bm), dtype=torch.float32, device=dev)
+    prev = torch.empty((n_sent, bm), dtype=torch.int32, device=dev)
+    tok = torch.empty((n_sent, bm), dtype=torch.int32, device=dev)
+    ws = workspace(int(lib.skhip_beam_topk_ws_bytes(n_sent, bm, V)))
+    rc = lib.skhip_beam_topk(_ptr(logits), _ptr(scores_in), _ptr(scores_out), _ptr(prev), _ptr(tok), _ptr(ws),
+                             n_sent, bm, V, int(first_step), _stream())
+    _check(rc, "skhip_beam_topk")
+    return scores_out, prev, tok
+
+
+def gather_rows(src, dst, src_row, n_rows, row_elems, src_stride, dst_stride):
+    lib = load()
+    rc = lib.skhip_gather_rows(_ptr(src), _ptr(dst), _ptr(src_row), n_rows, row_elems, src_stride, dst_stride,
+                               dcode(src.dtype), _stream())
+    _check(rc, "skhip_gather_rows")

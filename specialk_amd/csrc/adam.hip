@@ -1,0 +1,131 @@
+// Multi-tensor Adam and dtype conversion helpers.
+// Replaces optim.Adam.step as configured by setup_optimiser (lib/TransformerModel.py:159-165:
+// betas (0.9, 0.98), eps 1e-9, no weight decay) under ScheduledOptim
+// (lib/transformer/Optim.py:15-39).  The reference issues several small launches per
+// parameter tensor; here one launch walks every tensor: blockIdx.y selects the tensor,
+// blockIdx.x strides over its elements.  HBM-bound: 16 B read (p, g, m, v) + 12 B written
+// per element (+2 B for the bf16 working copy).
+#include "common.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void adam_multi_kernel(const uint64_t* __restrict__ pp, const uint64_t* __restrict__ gp,
+                                                         const uint64_t* __restrict__ mp, const uint64_t* __restrict__ vp,
+                                                         const uint64_t* __restrict__ bp, const int64_t* __restrict__ counts,
+                                                         float step_size, float beta1, float beta2, float eps,
+                                                         float bc2_sqrt, float grad_scale) {
+  const int t = blockIdx.y;
+  const int64_t n = counts[t];
+  float* p = (float*)pp[t];
+  const float* g = (const float*)gp[t];
+  float* m = (float*)mp[t];
+  float* v = (float*)vp[t];
+  bf16_t* b = bp ? (bf16_t*)bp[t] : nullptr;
+  const float w1 = 1.0f - beta1, w2 = 1.0f - beta2;
+  const int64_t n4 = n >> 2;
+  const bool vec = (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0;
+  auto upd = [&](float& pv, float gv, float& mv, float& vv) {
+    gv *= grad_scale;
+    mv = mv + w1 * (gv - mv);            // exp_avg.lerp_(grad, 1 - beta1)
+    vv = vv * beta2 + w2 * gv * gv;      // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1-beta2)
+    float denom = sqrtf(vv) / bc2_sqrt + eps;
+    pv = pv - step_size * (mv / denom);  // param.addcdiv_(exp_avg, denom, value=-step_size)
+  };
+  if (vec) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+      float4 P = ((float4*)p)[i], G = ((const float4*)g)[i], M = ((float4*)m)[i], V = ((float4*)v)[i];
+      upd(P.x, G.x, M.x, V.x); upd(P.y, G.y, M.y, V.y); upd(P.z, G.z, M.z, V.z); upd(P.w, G.w, M.w, V.w);
+      ((float4*)p)[i] = P; ((float4*)m)[i] = M; ((float4*)v)[i] = V;
+      if (b) { b[4 * i] = f32_to_bf16(P.x); b[4 * i + 1] = f32_to_bf16(P.y); b[4 * i + 2] = f32_to_bf16(P.z); b[4 * i + 3] = f32_to_bf16(P.w); }
+    }
+    for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+      float P = p[i], M = m[i], V = v[i];
+      upd(P, g[i], M, V);
+      p[i] = P; m[i] = M; v[i] = V;
+      if (b) b[i] = f32_to_bf16(P);
+    }
+  } else {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+      float P = p[i], M = m[i], V = v[i];
+      upd(P, g[i], M, V);
+      p[i] = P; m[i] = M; v[i] = V;
+      if (b) b[i] = f32_to_bf16(P);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void cast_multi_kernel(const uint64_t* __restrict__ sp, const uint64_t* __restrict__ dp,
+                                                         const int64_t* __restrict__ counts) {
+  const int t = blockIdx.y;
+  const int64_t n = counts[t];
+  const float* s = (const float*)sp[t];
+  bf16_t* d = (bf16_t*)dp[t];
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) d[i] = f32_to_bf16(s[i]);
+}
+
+template <typename TS, typename TD>
+__global__ __launch_bounds__(256) void convert_kernel(const TS* __restrict__ s, TD* __restrict__ d, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+    d[i] = Cvt<TD>::from_f32(Cvt<TS>::to_f32(s[i]));
+}
+
+unsigned blocks_for(int64_t max_count, int per_thread) {
+  int64_t b = (max_count + 256 * per_thread - 1) / (256 * per_thread);
+  if (b < 1) b = 1;
+  if (b > 1024) b = 1024;
+  return (unsigned)b;
+}
+
+}  // namespace
+
+extern "C" int skhip_adam_multi(const uint64_t* param_ptrs, const uint64_t* grad_ptrs, const uint64_t* m_ptrs,
+                                const uint64_t* v_ptrs, const uint64_t* bf16_copy_ptrs, const int64_t* counts, int n,
+                                int64_t max_count, float lr, float beta1, float beta2, float eps, int step,
+                                float grad_scale, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SK_CHECK_ARG(n >= 0 && n <= 65535, "skhip_adam_multi: n=%d", n);
+  SK_CHECK_ARG(step >= 1, "skhip_adam_multi: step=%d must start at 1", step);
+  if (n == 0) return SK_OK;
+  SK_CHECK_ARG(param_ptrs && grad_ptrs && m_ptrs && v_ptrs && counts, "skhip_adam_multi: null table");
+  // Scalars as torch computes them: Python doubles, rounded to fp32 where they meet tensors.
+  double bc1 = 1.0 - pow((double)beta1, (double)step);
+  double bc2 = 1.0 - pow((double)beta2, (double)step);
+  float step_size = (float)((double)lr / bc1);
+  float bc2_sqrt = (float)sqrt(bc2);
+  dim3 grid(blocks_for(max_count, 4), (unsigned)n);
+  hipLaunchKernelGGL(adam_multi_kernel, grid, dim3(256), 0, stream, param_ptrs, grad_ptrs, m_ptrs, v_ptrs,
+                     bf16_copy_ptrs, counts, step_size, beta1, beta2, eps, bc2_sqrt, grad_scale);
+  SK_CHECK_LAUNCH("skhip_adam_multi");
+  return SK_OK;
+}
+
+extern "C" int skhip_cast_multi(const uint64_t* src_f32_ptrs, const uint64_t* dst_bf16_ptrs, const int64_t* counts,
+                                int n, int64_t max_count, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SK_CHECK_ARG(n >= 0 && n <= 65535, "skhip_cast_multi: n=%d", n);
+  if (n == 0) return SK_OK;
+  SK_CHECK_ARG(src_f32_ptrs && dst_bf16_ptrs && counts, "skhip_cast_multi: null table");
+  dim3 grid(blocks_for(max_count, 4), (unsigned)n);
+  hipLaunchKernelGGL(cast_multi_kernel, grid, dim3(256), 0, stream, src_f32_ptrs, dst_bf16_ptrs, counts);
+  SK_CHECK_LAUNCH("skhip_cast_multi");
+  return SK_OK;
+}
+
+extern "C" int skhip_convert(const void* src, void* dst, int64_t n, int src_dtype, int dst_dtype, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SK_CHECK_ARG((src_dtype == SK_F32 || src_dtype == SK_BF16) && (dst_dtype == SK_F32 || dst_dtype == SK_BF16),
+               "skhip_convert: bad dtype");
+  if (n == 0) return SK_OK;
+  SK_CHECK_ARG(src && dst, "skhip_convert: null pointer");
+  dim3 grid(blocks_for(n, 4));
+  if (src_dtype == SK_F32 && dst_dtype == SK_BF16)
+    hipLaunchKernelGGL((convert_kernel<float, bf16_t>), grid, dim3(256), 0, stream, (const float*)src, (bf16_t*)dst, n);
+  else if (src_dtype == SK_BF16 && dst_dtype == SK_F32)
+    hipLaunchKernelGGL((convert_kernel<bf16_t, float>), grid, dim3(256), 0, stream, (const bf16_t*)src, (float*)dst, n);
+  else if (src_dtype == SK_F32)
+    hipLaunchKernelGGL((convert_kernel<float, float>), grid, dim3(256), 0, stream, (const float*)src, (float*)dst, n);
+  else
+    hipLaunchKernelGGL((convert_kernel<bf16_t, bf16_t>), grid, dim3(256), 0, stream, (const bf16_t*)src, (bf16_t*)dst, n);
+  SK_CHECK_LAUNCH("skhip_convert");
+  return SK_OK;
+}

@@ -1,0 +1,292 @@
+// Beam-search decode step kernels: single-query attention over a KV cache, fused
+// log-softmax + beam expansion + top-k, and cache row gather.
+//
+// The reference re-runs the whole decoder on the whole prefix at every step
+// (lib/transformer/Translator.py:130-140) and keeps beams as Python objects whose advance()
+// calls topk twice and syncs with .item() (lib/transformer/Beam.py:46-79).  Here a step only
+// computes the newest position against cached keys/values, and the beam bookkeeping of all
+// sentences is two launches with no host round trip.
+#include "common.h"
+
+namespace {
+
+// ------------------------------------------------------------------ single-query attention
+// One wave per (row, head).  Keys sweep in tiles of 64 (lane = key), online softmax, then
+// each lane accumulates output column(s) lane (+64) with v_readlane broadcasts.  K and V are
+// read straight from HBM/L2 once: the step is bandwidth-bound on the cache.
+template <typename T>
+__global__ __launch_bounds__(256) void decode_attn_kernel(const T* __restrict__ q, const T* __restrict__ Kc,
+                                                          const T* __restrict__ Vc, T* __restrict__ out,
+                                                          const int32_t* __restrict__ kv_len,
+                                                          const uint8_t* __restrict__ key_pad, int R, int H, int len,
+                                                          int Lmax, int dk, int dv, int64_t ldq, int64_t ldo, float scale) {
+  __shared__ float qs[4][128];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int pair = blockIdx.x * 4 + wave;
+  if (pair >= R * H) return;  // wave-uniform
+  const int r = pair / H, h = pair - r * H;
+  const int n = kv_len ? kv_len[r] : len;
+  for (int c = lane; c < dk; c += 64) qs[wave][c] = Cvt<T>::to_f32(q[(int64_t)r * ldq + h * dk + c]) * scale;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  const T* Kr = Kc + (int64_t)r * Lmax * H * dk + h * dk;
+  const T* Vr = Vc + (int64_t)r * Lmax * H * dv + h * dv;
+  float m = -INFINITY, l = 0.f, acc0 = 0.f, acc1 = 0.f;
+  const int c0 = lane < dv ? lane : 0, c1 = lane + 64 < dv ? lane + 64 : 0;
+  for (int j0 = 0; j0 < n; j0 += 64) {
+    const int j = j0 + lane;
+    float s = -INFINITY;
+    if (j < n && !(key_pad && key_pad[(int64_t)r * Lmax + j])) {
+      const T* kr = Kr + (int64_t)j * H * dk;
+      float a = 0.f;
+      for (int c = 0; c < dk; ++c) a += qs[wave][c] * Cvt<T>::to_f32(kr[c]);
+      s = a;
+    }
+    float mn = fmaxf(m, wave_max(s));
+    float pr = 0.f, alpha = 1.f;
+    if (mn != -INFINITY) { alpha = expf(m - mn); pr = expf(s - mn); }
+    l = l * alpha + wave_sum(pr);
+    m = mn;
+    acc0 *= alpha; acc1 *= alpha;
+    const int cnt = min(64, n - j0);
+    for (int t = 0; t < cnt; ++t) {
+      float cf = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pr), t));
+      const T* vr = Vr + (int64_t)(j0 + t) * H * dv;
+      acc0 += cf * Cvt<T>::to_f32(vr[c0]);
+      if (dv > 64) acc1 += cf * Cvt<T>::to_f32(vr[c1]);
+    }
+  }
+  const float inv = 1.0f / l;
+  if (lane < dv) out[(int64_t)r * ldo + h * dv + lane] = Cvt<T>::from_f32(acc0 * inv);
+  if (lane + 64 < dv) out[(int64_t)r * ldo + h * dv + lane + 64] = Cvt<T>::from_f32(acc1 * inv);
+}
+
+// ------------------------------------------------------------------ beam top-k
+// (value, index) ordering used everywhere: larger value first, lower index on ties.
+__device__ __forceinline__ bool better(float v, int i, float ov, int oi) { return v > ov || (v == ov && i < oi); }
+
+__device__ __forceinline__ void wave_argbest(float& v, int& i) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    float ov = __shfl_xor(v, o, 64);
+    int oi = __shfl_xor(i, o, 64);
+    if (better(ov, oi, v, i)) { v = ov; i = oi; }
+  }
+}
+
+// Pass A: one block per (sentence, beam) row: log-sum-exp over V, then the row's best KC
+// tokens.  Candidate value = (x - max) - log(sum) + score_in, the same operation order as
+// F.log_softmax followed by `word_prob + scores` (Translator.py:137, Beam.py:52).
+template <int KC>
+__global__ __launch_bounds__(256) void beam_row_topk_kernel(const float* __restrict__ logits,
+                                                            const float* __restrict__ scores_in,
+                                                            float* __restrict__ cand_val, int32_t* __restrict__ cand_idx,
+                                                            int bm, int64_t V, int first_step) {
+  __shared__ float s_red[4];
+  __shared__ float s_val[4];
+  __shared__ int s_idx[4];
+  __shared__ float s_best_v;
+  __shared__ int s_best_i;
+  const int row = blockIdx.x, beam = row % bm;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* cv = cand_val + (int64_t)row * bm;
+  int32_t* ci = cand_idx + (int64_t)row * bm;
+  if (first_step && beam != 0) {  // Beam.py:51-54: only word_prob[0] takes part in the first step
+    if (threadIdx.x < bm) { cv[threadIdx.x] = -INFINITY; ci[threadIdx.x] = 0x7fffffff; }
+    return;
+  }
+  const float* x = logits + (int64_t)row * V;
+  // thread-local top-KC, kept sorted (best first)
+  float tv[KC];
+  int ti[KC];
+#pragma unroll
+  for (int k = 0; k < KC; ++k) { tv[k] = -INFINITY; ti[k] = 0x7fffffff; }
+  float mx = -INFINITY;
+  for (int64_t c = threadIdx.x; c < V; c += 256) {
+    float v = x[c];
+    mx = fmaxf(mx, v);
+    if (better(v, (int)c, tv[KC - 1], ti[KC - 1])) {
+      tv[KC - 1] = v; ti[KC - 1] = (int)c;
+#pragma unroll
+      for (int k = KC - 1; k > 0; --k)
+        if (better(tv[k], ti[k], tv[k - 1], ti[k - 1])) {
+          float fv = tv[k]; tv[k] = tv[k - 1]; tv[k - 1] = fv;
+          int fi = ti[k]; ti[k] = ti[k - 1]; ti[k - 1] = fi;
+        }
+    }
+  }
+  mx = wave_max(mx);
+  if (lane == 0) s_red[wave] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+  __syncthreads();
+  float se = 0.f;
+  for (int64_t c = threadIdx.x; c < V; c += 256) se += expf(x[c] - mx);
+  se = wave_sum(se);
+  if (lane == 0) s_red[wave] = se;
+  __syncthreads();
+  se = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+  const float logse = logf(se);
+  const float sc = first_step ? 0.f : scores_in[row];
+  // bm rounds: block-wide best of the per-thread heads; the winner pops its head.
+  for (int round = 0; round < bm; ++round) {
+    float v = tv[0];
+    int i = ti[0];
+    wave_argbest(v, i);
+    if (lane == 0) { s_val[wave] = v; s_idx[wave] = i; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float bv = s_val[0]; int bi = s_idx[0];
+#pragma unroll
+      for (int w = 1; w < 4; ++w) if (better(s_val[w], s_idx[w], bv, bi)) { bv = s_val[w]; bi = s_idx[w]; }
+      s_best_v = bv; s_best_i = bi;
+      float lp = (bv - mx) - logse;
+      cv[round] = first_step ? lp : lp + sc;
+      ci[round] = bi;
+    }
+    __syncthreads();
+    if (ti[0] == s_best_i && s_best_i != 0x7fffffff) {
+#pragma unroll
+      for (int k = 0; k < KC - 1; ++k) { tv[k] = tv[k + 1]; ti[k] = ti[k + 1]; }
+      tv[KC - 1] = -INFINITY; ti[KC - 1] = 0x7fffffff;
+    }
+    __syncthreads();
+  }
+}
+
+// Pass B: one wave per sentence merges its bm*bm row candidates into the new beam,
+// ordered like flat_beam_lk.topk(size, 0, True, True) with flat id = beam*V + token.
+__global__ __launch_bounds__(64) void beam_merge_kernel(const float* __restrict__ cand_val,
+                                                        const int32_t* __restrict__ cand_idx,
+                                                        float* __restrict__ scores_out, int32_t* __restrict__ prev_out,
+                                                        int32_t* __restrict__ tok_out, int bm, int64_t V) {
+  const int sent = blockIdx.x, lane = threadIdx.x;
+  const int n = bm * bm;  // <= 256
+  float v[4];
+  int id[4];  // index into the sentence's candidate list; flat order = (beam, rank) and within a
+              // beam candidates are already sorted, so comparing (value, beam*V+tok) needs the token
+  long long flat[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    int e = lane + 64 * k;
+    if (e < n) {
+      v[k] = cand_val[(int64_t)sent * n + e];
+      int tok = cand_idx[(int64_t)sent * n + e];
+      id[k] = e;
+      flat[k] = tok == 0x7fffffff ? 0x7fffffffffffffffll : (long long)(e / bm) * V + tok;
+    } else { v[k] = -INFINITY; id[k] = -1; flat[k] = 0x7fffffffffffffffll; }
+  }
+  for (int round = 0; round < bm; ++round) {
+    float bv = -INFINITY; long long bf = 0x7fffffffffffffffll; int bk = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (v[k] > bv || (v[k] == bv && flat[k] < bf)) { bv = v[k]; bf = flat[k]; bk = k; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      float ov = __shfl_xor(bv, o, 64);
+      long long of = __shfl_xor(bf, o, 64);
+      if (ov > bv || (ov == bv && of < bf)) { bv = ov; bf = of; }
+    }
+    // the unique owner of (bv, bf) retires it
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (flat[k] == bf && v[k] == bv && bf != 0x7fffffffffffffffll) { v[k] = -INFINITY; flat[k] = 0x7fffffffffffffffll; }
+    (void)bk;
+    if (lane == 0) {
+      int64_t o = (int64_t)sent * bm + round;
+      scores_out[o] = bv;
+      prev_out[o] = bf == 0x7fffffffffffffffll ? 0 : (int32_t)(bf / V);
+      tok_out[o] = bf == 0x7fffffffffffffffll ? 0 : (int32_t)(bf % V);
+    }
+  }
+}
+
+// ------------------------------------------------------------------ row gather
+template <int VB>  // bytes per access
+__global__ __launch_bounds__(256) void gather_rows_kernel(const char* __restrict__ src, char* __restrict__ dst,
+                                                          const int32_t* __restrict__ src_row, int64_t row_bytes,
+                                                          int64_t src_stride_b, int64_t dst_stride_b) {
+  const int64_t r = blockIdx.y;
+  const char* s = src + (int64_t)src_row[r] * src_stride_b;
+  char* d = dst + r * dst_stride_b;
+  for (int64_t o = ((int64_t)blockIdx.x * 256 + threadIdx.x) * VB; o < row_bytes; o += (int64_t)gridDim.x * 256 * VB) {
+    if (VB == 16) *(uint4*)(d + o) = *(const uint4*)(s + o);
+    else if (VB == 4) *(uint32_t*)(d + o) = *(const uint32_t*)(s + o);
+    else *(uint16_t*)(d + o) = *(const uint16_t*)(s + o);
+  }
+}
+
+}  // namespace
+
+extern "C" int skhip_decode_attn(const void* q, const void* Kc, const void* Vc, void* out, const int32_t* kv_len,
+                                 const uint8_t* key_pad, int R, int n_head, int len, int Lmax, int dk, int dv, int64_t ldq,
+                                 int64_t ldo, float scale, int dtype, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SK_CHECK_ARG(dtype == SK_F32 || dtype == SK_BF16, "skhip_decode_attn: bad dtype");
+  SK_CHECK_ARG(R >= 0 && n_head > 0 && dk > 0 && dv > 0 && dk <= 128 && dv <= 128, "skhip_decode_attn: bad shape");
+  SK_CHECK_ARG(len >= 0 && len <= Lmax, "skhip_decode_attn: len=%d exceeds Lmax=%d", len, Lmax);
+  if (R == 0) return SK_OK;
+  SK_CHECK_ARG(q && Kc && Vc && out, "skhip_decode_attn: null pointer");
+  unsigned blocks = (unsigned)(((int64_t)R * n_head + 3) / 4);
+  if (dtype == SK_BF16)
+    hipLaunchKernelGGL((decode_attn_kernel<bf16_t>), dim3(blocks), dim3(256), 0, stream, (const bf16_t*)q,
+                       (const bf16_t*)Kc, (const bf16_t*)Vc, (bf16_t*)out, kv_len, key_pad, R, n_head, len, Lmax, dk, dv,
+                       ldq, ldo, scale);
+  else
+    hipLaunchKernelGGL((decode_attn_kernel<float>), dim3(blocks), dim3(256), 0, stream, (const float*)q, (const float*)Kc,
+                       (const float*)Vc, (float*)out, kv_len, key_pad, R, n_head, len, Lmax, dk, dv, ldq, ldo, scale);
+  SK_CHECK_LAUNCH("skhip_decode_attn");
+  return SK_OK;
+}
+
+extern "C" int64_t skhip_beam_topk_ws_bytes(int n_sent, int bm, int64_t V) {
+  (void)V;
+  return (int64_t)n_sent * bm * bm * 8;
+}
+
+extern "C" int skhip_beam_topk(const float* logits, const float* scores_in, float* scores_out, int32_t* prev_out,
+                               int32_t* tok_out, void* ws, int n_sent, int bm, int64_t V, int first_step, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SK_CHECK_ARG(bm >= 1 && bm <= 16, "skhip_beam_topk: beam size %d not in 1..16", bm);
+  SK_CHECK_ARG(V >= bm && V < (1ll << 31), "skhip_beam_topk: V=%lld", (long long)V);
+  if (n_sent == 0) return SK_OK;
+  SK_CHECK_ARG(logits && scores_in && scores_out && prev_out && tok_out && ws, "skhip_beam_topk: null pointer");
+  float* cv = (float*)ws;
+  int32_t* ci = (int32_t*)(cv + (int64_t)n_sent * bm * bm);
+  dim3 grid((unsigned)(n_sent * bm));
+#define BEAM_A(KC) hipLaunchKernelGGL((beam_row_topk_kernel<KC>), grid, dim3(256), 0, stream, logits, scores_in, cv, ci, bm, V, first_step)
+  if (bm <= 1) BEAM_A(1);
+  else if (bm <= 2) BEAM_A(2);
+  else if (bm <= 4) BEAM_A(4);
+  else if (bm <= 8) BEAM_A(8);
+  else BEAM_A(16);
+  SK_CHECK_LAUNCH("skhip_beam_topk(rows)");
+  hipLaunchKernelGGL(beam_merge_kernel, dim3((unsigned)n_sent), dim3(64), 0, stream, cv, ci, scores_out, prev_out, tok_out, bm, V);
+  SK_CHECK_LAUNCH("skhip_beam_topk(merge)");
+  return SK_OK;
+}
+
+extern "C" int skhip_gather_rows(const void* src, void* dst, const int32_t* src_row, int64_t n_rows, int64_t row_elems,
+                                 int64_t src_stride, int64_t dst_stride, int dtype, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SK_CHECK_ARG(dtype == SK_F32 || dtype == SK_BF16, "skhip_gather_rows: bad dtype");
+  SK_CHECK_ARG(n_rows >= 0 && n_rows <= 65535 && row_elems >= 0, "skhip_gather_rows: bad shape");
+  if (n_rows == 0 || row_elems == 0) return SK_OK;
+  SK_CHECK_ARG(src && dst && src_row && src != dst, "skhip_gather_rows: null or aliased pointer");
+  const int esz = dtype == SK_BF16 ? 2 : 4;
+  const int64_t rb = row_elems * esz, ss = src_stride * esz, ds = dst_stride * esz;
+  const bool v16 = rb % 16 == 0 && ss % 16 == 0 && ds % 16 == 0 && (uintptr_t)src % 16 == 0 && (uintptr_t)dst % 16 == 0;
+  const int vb = v16 ? 16 : esz;
+  int64_t bx = (rb / vb + 255) / 256;
+  if (bx > 64) bx = 64;
+  if (bx < 1) bx = 1;
+  dim3 grid((unsigned)bx, (unsigned)n_rows);
+  if (vb == 16)
+    hipLaunchKernelGGL((gather_rows_kernel<16>), grid, dim3(256), 0, stream, (const char*)src, (char*)dst, src_row, rb, ss, ds);
+  else if (vb == 4)
+    hipLaunchKernelGGL((gather_rows_kernel<4>), grid, dim3(256), 0, stream, (const char*)src, (char*)dst, src_row, rb, ss, ds);
+  else
+    hipLaunchKernelGGL((gather_rows_kernel<2>), grid, dim3(256), 0, stream, (const char*)src, (char*)dst, src_row, rb, ss, ds);
+  SK_CHECK_LAUNCH("skhip_gather_rows");
+  return SK_OK;
+}

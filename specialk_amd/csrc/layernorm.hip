@@ -1,0 +1,248 @@
+// Fused  y = LayerNorm(res + dropout(x)) * gamma + beta,  pad rows zeroed  — forward and
+// backward.  Replaces `self.layer_norm(self.dropout(out) + residual)`
+// (lib/transformer/SubLayers.py:62-63,83-84) and the `*= non_pad_mask` after every sublayer
+// (lib/transformer/Layers.py:22,25,50,55,58).
+//
+// HBM-bound: one wave per row, 16-byte loads per lane, the row lives in registers between
+// the statistics and the normalisation, so each element is read once and written once.
+// Statistics are fp32 and two-pass (mean, then centred variance) like torch's.
+#include "common.h"
+
+namespace {
+
+constexpr int LN_MAX_D = 2048;    // a row is held in registers: 32 values per lane
+constexpr int LN_MAX_BLOCKS = 1024;
+
+template <typename T>
+__global__ __launch_bounds__(256) void add_ln_fwd_kernel(const T* __restrict__ x, const T* __restrict__ res,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         const uint8_t* __restrict__ row_pad, T* __restrict__ y,
+                                                         float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                         int64_t T_rows, int d, float eps, uint32_t drop_thr,
+                                                         float keep_scale, uint64_t seed) {
+  constexpr int VN = Vec16<T>::N;
+  constexpr int MAXV = LN_MAX_D / (64 * VN);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nvec = d / VN;  // vectors per row
+  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < T_rows; row += (int64_t)gridDim.x * 4) {
+    const T* xr = x + row * d;
+    const T* rr = res + row * d;
+    float z[MAXV][VN];
+    float sum = 0.f;
+#pragma unroll
+    for (int v = 0; v < MAXV; ++v) {
+      int vi = lane + v * 64;
+      if (vi < nvec) {
+        Vec16<T> a, b;
+        a.v = *(const decltype(a.v)*)(xr + vi * VN);
+        b.v = *(const decltype(b.v)*)(rr + vi * VN);
+#pragma unroll
+        for (int j = 0; j < VN; ++j) {
+          float xv = a.get(j);
+          if (drop_thr) xv = sk_keep(seed, (uint64_t)(row * d + vi * VN + j), drop_thr) ? xv * keep_scale : 0.f;
+          z[v][j] = b.get(j) + xv;
+          sum += z[v][j];
+        }
+      }
+    }
+    const float mean = wave_sum(sum) / (float)d;
+    float sq = 0.f;
+#pragma unroll
+    for (int v = 0; v < MAXV; ++v)
+      if (lane + v * 64 < nvec)
+#pragma unroll
+        for (int j = 0; j < VN; ++j) { float c = z[v][j] - mean; sq += c * c; }
+    const float var = wave_sum(sq) / (float)d;
+    const float rstd = 1.0f / sqrtf(var + eps);
+    const bool pad = row_pad && row_pad[row];
+    if (lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
+    T* yr = y + row * d;
+#pragma unroll
+    for (int v = 0; v < MAXV; ++v) {
+      int vi = lane + v * 64;
+      if (vi < nvec) {
+        Vec16<T> o;
+        const float4* g4 = (const float4*)(gamma + vi * VN);
+        const float4* b4 = (const float4*)(beta + vi * VN);
+#pragma unroll
+        for (int j4 = 0; j4 < VN / 4; ++j4) {
+          float4 g = g4[j4], b = b4[j4];
+          const float gg[4] = {g.x, g.y, g.z, g.w}, bb[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) {
+            int j = j4 * 4 + jj;
+            float val = (z[v][j] - mean) * rstd * gg[jj] + bb[jj];
+            o.set(j, pad ? 0.f : val);
+          }
+        }
+        *(decltype(o.v)*)(yr + vi * VN) = o.v;
+      }
+    }
+  }
+}
+
+// Backward.  Each block walks rows with a grid stride and keeps per-column partial sums of
+// dgamma / dbeta in registers; they are combined across the block's 4 waves through LDS and
+// written to partial[blockIdx][2][d]; a second kernel reduces over blocks in a fixed order.
+template <typename T>
+__global__ __launch_bounds__(256) void add_ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                         const T* __restrict__ res, const float* __restrict__ gamma,
+                                                         const uint8_t* __restrict__ row_pad,
+                                                         const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
+                                                         T* __restrict__ dx, T* __restrict__ dres, float* __restrict__ partial,
+                                                         int64_t T_rows, int d, uint32_t drop_thr, float keep_scale,
+                                                         uint64_t seed) {
+  constexpr int VN = Vec16<T>::N;
+  constexpr int MAXV = LN_MAX_D / (64 * VN);
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* red = (float*)smem_raw;  // [4 waves][2][d]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nvec = d / VN;
+  float pg[MAXV][VN], pb[MAXV][VN];
+#pragma unroll
+  for (int v = 0; v < MAXV; ++v)
+#pragma unroll
+    for (int j = 0; j < VN; ++j) { pg[v][j] = 0.f; pb[v][j] = 0.f; }
+
+  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < T_rows; row += (int64_t)gridDim.x * 4) {
+    const bool pad = row_pad && row_pad[row];
+    const float mean = mean_in[row], rstd = rstd_in[row];
+    float xhat[MAXV][VN], dxh[MAXV][VN];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int v = 0; v < MAXV; ++v) {
+      int vi = lane + v * 64;
+      if (vi < nvec) {
+        Vec16<T> a, b, g;
+        a.v = *(const decltype(a.v)*)(x + row * d + vi * VN);
+        b.v = *(const decltype(b.v)*)(res + row * d + vi * VN);
+        g.v = *(const decltype(g.v)*)(dy + row * d + vi * VN);
+#pragma unroll
+        for (int j = 0; j < VN; ++j) {
+          float xv = a.get(j);
+          if (drop_thr) xv = sk_keep(seed, (uint64_t)(row * d + vi * VN + j), drop_thr) ? xv * keep_scale : 0.f;
+          float xh = (b.get(j) + xv - mean) * rstd;
+          float dyv = pad ? 0.f : g.get(j);
+          float dh = dyv * gamma[vi * VN + j];
+          xhat[v][j] = xh;
+          dxh[v][j] = dh;
+          pg[v][j] += dyv * xh;
+          pb[v][j] += dyv;
+          s1 += dh;
+          s2 += dh * xh;
+        }
+      }
+    }
+    const float c1 = wave_sum(s1) / (float)d, c2 = wave_sum(s2) / (float)d;
+#pragma unroll
+    for (int v = 0; v < MAXV; ++v) {
+      int vi = lane + v * 64;
+      if (vi < nvec) {
+        Vec16<T> o1, o2;
+#pragma unroll
+        for (int j = 0; j < VN; ++j) {
+          float dz = rstd * (dxh[v][j] - c1 - xhat[v][j] * c2);
+          o1.set(j, dz);
+          float dxv = dz;
+          if (drop_thr) dxv = sk_keep(seed, (uint64_t)(row * d + vi * VN + j), drop_thr) ? dz * keep_scale : 0.f;
+          o2.set(j, dxv);
+        }
+        *(decltype(o1.v)*)(dres + row * d + vi * VN) = o1.v;
+        if (dx != dres) *(decltype(o2.v)*)(dx + row * d + vi * VN) = o2.v;
+      }
+    }
+  }
+  // block reduction of the parameter-gradient partials
+#pragma unroll
+  for (int v = 0; v < MAXV; ++v) {
+    int vi = lane + v * 64;
+    if (vi < nvec)
+#pragma unroll
+      for (int j = 0; j < VN; ++j) {
+        red[(wave * 2 + 0) * d + vi * VN + j] = pg[v][j];
+        red[(wave * 2 + 1) * d + vi * VN + j] = pb[v][j];
+      }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * d; i += 256) {
+    float s = red[i] + red[2 * d + i] + red[4 * d + i] + red[6 * d + i];
+    partial[(int64_t)blockIdx.x * 2 * d + i] = s;
+  }
+}
+
+__global__ void ln_param_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dgamma,
+                                       float* __restrict__ dbeta, int d, int nblocks, int accumulate) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 2 * d) return;
+  float s = 0.f;
+  for (int b = 0; b < nblocks; ++b) s += partial[(int64_t)b * 2 * d + i];
+  float* out = i < d ? dgamma + i : dbeta + (i - d);
+  *out = accumulate ? *out + s : s;
+}
+
+int check_d(const char* who, int d, int dtype) {
+  int vn = dtype == SK_BF16 ? 8 : 4;
+  SK_CHECK_ARG(dtype == SK_F32 || dtype == SK_BF16, "%s: bad dtype %d", who, dtype);
+  SK_CHECK_ARG(d > 0 && d % vn == 0 && d <= LN_MAX_D, "%s: d=%d must be a multiple of %d and <= %d", who, d, vn,
+               LN_MAX_D);
+  return SK_OK;
+}
+
+}  // namespace
+
+extern "C" int skhip_add_ln_fwd(const void* x, const void* res, const float* gamma, const float* beta,
+                                const uint8_t* row_pad, void* y, float* mean, float* rstd, int64_t T, int d, float eps,
+                                float p_drop, uint64_t seed, int dtype, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  int rc = check_d("skhip_add_ln_fwd", d, dtype);
+  if (rc) return rc;
+  SK_CHECK_ARG(p_drop >= 0.f && p_drop < 1.f, "skhip_add_ln_fwd: p_drop=%f", p_drop);
+  if (T == 0) return SK_OK;
+  SK_CHECK_ARG(x && res && gamma && beta && y && mean && rstd, "skhip_add_ln_fwd: null pointer");
+  int64_t blocks = (T + 3) / 4;
+  if (blocks > 2048) blocks = 2048;
+  uint32_t thr = sk_drop_threshold(p_drop);
+  float ks = 1.0f / (1.0f - p_drop);
+  if (dtype == SK_BF16)
+    hipLaunchKernelGGL((add_ln_fwd_kernel<bf16_t>), dim3((unsigned)blocks), dim3(256), 0, stream, (const bf16_t*)x,
+                       (const bf16_t*)res, gamma, beta, row_pad, (bf16_t*)y, mean, rstd, T, d, eps, thr, ks, seed);
+  else
+    hipLaunchKernelGGL((add_ln_fwd_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, stream, (const float*)x,
+                       (const float*)res, gamma, beta, row_pad, (float*)y, mean, rstd, T, d, eps, thr, ks, seed);
+  SK_CHECK_LAUNCH("skhip_add_ln_fwd");
+  return SK_OK;
+}
+
+extern "C" int64_t skhip_add_ln_bwd_ws_floats(int d) { return (int64_t)LN_MAX_BLOCKS * 2 * d; }
+
+extern "C" int skhip_add_ln_bwd(const void* dy, const void* x, const void* res, const float* gamma,
+                                const uint8_t* row_pad, const float* mean, const float* rstd, void* dx, void* dres,
+                                float* dgamma, float* dbeta, float* partial_ws, int64_t T, int d, float p_drop,
+                                uint64_t seed, int accumulate, int dtype, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  int rc = check_d("skhip_add_ln_bwd", d, dtype);
+  if (rc) return rc;
+  SK_CHECK_ARG(p_drop >= 0.f && p_drop < 1.f, "skhip_add_ln_bwd: p_drop=%f", p_drop);
+  SK_CHECK_ARG(dy && x && res && gamma && mean && rstd && dx && dres && dgamma && dbeta && partial_ws,
+               "skhip_add_ln_bwd: null pointer");
+  SK_CHECK_ARG(p_drop == 0.f || dx != dres, "skhip_add_ln_bwd: dx may alias dres only without dropout");
+  int64_t blocks = (T + 3) / 4;
+  if (blocks > LN_MAX_BLOCKS) blocks = LN_MAX_BLOCKS;
+  if (blocks < 1) blocks = 1;
+  uint32_t thr = sk_drop_threshold(p_drop);
+  float ks = 1.0f / (1.0f - p_drop);
+  size_t smem = (size_t)8 * d * sizeof(float);
+  if (dtype == SK_BF16)
+    hipLaunchKernelGGL((add_ln_bwd_kernel<bf16_t>), dim3((unsigned)blocks), dim3(256), smem, stream, (const bf16_t*)dy,
+                       (const bf16_t*)x, (const bf16_t*)res, gamma, row_pad, mean, rstd, (bf16_t*)dx, (bf16_t*)dres,
+                       partial_ws, T, d, thr, ks, seed);
+  else
+    hipLaunchKernelGGL((add_ln_bwd_kernel<float>), dim3((unsigned)blocks), dim3(256), smem, stream, (const float*)dy,
+                       (const float*)x, (const float*)res, gamma, row_pad, mean, rstd, (float*)dx, (float*)dres,
+                       partial_ws, T, d, thr, ks, seed);
+  SK_CHECK_LAUNCH("skhip_add_ln_bwd");
+  hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((2 * d + 255) / 256), dim3(256), 0, stream, partial_ws, dgamma, dbeta,
+                     d, (int)blocks, accumulate);
+  SK_CHECK_LAUNCH("skhip_add_ln_bwd(param reduce)");
+  return SK_OK;
+}

@@ -1,0 +1,34 @@
+// Library-wide state: last-error string (thread local) and cached device properties.
+#include "common.h"
+#include <mutex>
+
+static thread_local char g_err[512] = "";
+static int g_num_cus = 0;
+static std::once_flag g_once;
+
+void sk_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+static void query_device() {
+  int dev = 0;
+  hipDeviceProp_t prop;
+  if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+    g_num_cus = prop.multiProcessorCount;
+  if (g_num_cus <= 0) g_num_cus = 256;  // MI355X
+}
+
+int sk_num_cus() {
+  std::call_once(g_once, query_device);
+  return g_num_cus;
+}
+
+extern "C" int skhip_init(void) {
+  sk_num_cus();
+  return SK_OK;
+}
+extern "C" const char* skhip_version(void) { return "specialk_hip 0.1 (gfx950)"; }
+extern "C" const char* skhip_last_error(void) { return g_err; }

@@ -1,0 +1,413 @@
+"""Kernel-level parity: every C-ABI entry point against a plain fp64/fp32 CPU computation of
+the same op (torch / the numpy oracle) and against the golden vectors.  GPU only."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import transformer_np as O
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+F32_RTOL = 1e-5   # north-star tolerance for the fp32 path
+BF16_RTOL = 2e-2  # north-star tolerance for bf16 storage
+
+
+@pytest.fixture(scope="module")
+def L():
+    from specialk_amd import _lib
+    _lib.load()
+    return _lib
+
+
+def rel_err(got, ref):
+    got = got.detach().double().cpu()
+    ref = ref.detach().double().cpu()
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    return ((got - ref).abs().max() / ref.abs().max().clamp_min(1e-30)).item()
+
+
+def tol(dtype):
+    return F32_RTOL if dtype == torch.float32 else BF16_RTOL
+
+
+def rnd(shape, dtype, g, scale=1.0):
+    return (torch.randn(shape, generator=g) * scale).to(dtype)
+
+
+# ------------------------------------------------------------------------------ GEMM
+GEMM_SHAPES = [(128, 128, 64), (200, 136, 72), (33, 17, 40), (1, 5, 8), (257, 512, 1000), (130, 70, 37)]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("layout", [0, 1, 2])
+def test_gemm_layouts(L, dtype, layout):
+    g = torch.Generator().manual_seed(layout * 7 + 1)
+    for (M, N, K) in GEMM_SHAPES:
+        A = rnd((K, M) if layout == 2 else (M, K), dtype, g)
+        B = rnd((N, K) if layout == 0 else (K, N), dtype, g)
+        ref = (A.double().t() if layout == 2 else A.double()) @ (B.double().t() if layout == 0 else B.double())
+        out = L.gemm(layout, A.to(DEV), B.to(DEV), M, N, K, A.shape[1], B.shape[1], split_k=False)
+        assert rel_err(out, ref) <= tol(dtype), (M, N, K)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gemm_epilogues(L, dtype):
+    g = torch.Generator().manual_seed(5)
+    M, N, K = 150, 200, 96
+    A, B = rnd((M, K), dtype, g), rnd((N, K), dtype, g)
+    bias = torch.randn(N, generator=g)
+    aux = rnd((M, N), dtype, g)
+    base = A.double() @ B.double().t()
+    Ad, Bd = A.to(DEV), B.to(DEV)
+    out = L.gemm(L.GEMM_NT, Ad, Bd, M, N, K, K, K, bias=bias.to(DEV), epilogue=L.EPI_RELU, alpha=0.5)
+    assert rel_err(out, torch.relu(0.5 * base + bias.double())) <= tol(dtype)
+    out = L.gemm(L.GEMM_NT, Ad, Bd, M, N, K, K, K, aux=aux.to(DEV), epilogue=L.EPI_RELU_MASK)
+    assert rel_err(out, base * (aux.double() > 0)) <= tol(dtype)
+    # accumulate into an fp32 C (weight-gradient style) and strided output
+    C = torch.randn(M, N + 8, generator=g)
+    Cd = C.to(DEV)
+    L.gemm(L.GEMM_NT, Ad, Bd, M, N, K, K, K, out=Cd, ldc=N + 8, epilogue=L.EPI_ACCUM)
+    assert rel_err(Cd[:, :N], base + C[:, :N].double()) <= tol(dtype)
+    assert torch.equal(Cd[:, N:].cpu(), C[:, N:])
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gemm_splitk_wgrad(L, dtype):
+    """Weight-gradient shape: tiny output, long contraction -> deterministic split-K."""
+    g = torch.Generator().manual_seed(9)
+    T, N, K = 5000, 96, 160
+    dY, X = rnd((T, N), dtype, g), rnd((T, K), dtype, g)
+    ref = dY.double().t() @ X.double()
+    outs = [L.gemm(L.GEMM_TN, dY.to(DEV), X.to(DEV), N, K, T, N, K, out_dtype=torch.float32) for _ in range(2)]
+    assert rel_err(outs[0], ref) <= (F32_RTOL if dtype == torch.float32 else 2e-3)
+    assert torch.equal(outs[0], outs[1]), "split-K must be bitwise reproducible"
+
+
+def test_colsum(L):
+    g = torch.Generator().manual_seed(3)
+    for dtype in (torch.float32, torch.bfloat16):
+        X = rnd((777, 130), dtype, g)
+        out = L.colsum(X.to(DEV), 777, 130, 130)
+        assert rel_err(out, X.double().sum(0)) <= 1e-5
+
+
+# ------------------------------------------------------------------------------ attention
+def run_attn(L, q, k, v, keypad, causal, dtype, dense=None, p_drop=0.0, seed=0, want_p=False):
+    """q (B,Lq,H,dk) etc. as torch CPU tensors; returns O (B,Lq,H,dv), LSE and a closure for bwd."""
+    B, Lq, H, dk = q.shape
+    Lk, dv = k.shape[1], v.shape[3]
+    qd, kd, vd = (t.to(dtype).to(DEV).contiguous() for t in (q, k, v))
+    o = torch.empty((B, Lq, H, dv), dtype=dtype, device=DEV)
+    lse = torch.empty((B, H, Lq), dtype=torch.float32, device=DEV)
+    kp = keypad.to(torch.uint8).to(DEV) if keypad is not None else None
+    dm = dense.to(torch.uint8).to(DEV) if dense is not None else None
+    P = torch.empty((H, B, Lq, Lk), dtype=dtype, device=DEV) if want_p else None
+    scale = 1.0 / np.sqrt(dk)
+    L.attn_fwd(qd, kd, vd, o, lse, B, H, Lq, Lk, dk, dv, H * dk, H * dk, H * dv, H * dv, scale, key_pad=kp,
+               dense_mask=dm, causal=causal, p_drop=p_drop, seed=seed, P_out=P)
+
+    def bwd(do):
+        dod = do.to(dtype).to(DEV).contiguous()
+        dq, dk_, dv_ = torch.empty_like(qd), torch.empty_like(kd), torch.empty_like(vd)
+        delta = torch.empty((B, H, Lq), dtype=torch.float32, device=DEV)
+        L.attn_bwd(qd, kd, vd, o, dod, lse, dq, dk_, dv_, delta, B, H, Lq, Lk, dk, dv, H * dk, H * dk, H * dv, H * dv,
+                   H * dk, H * dk, H * dv, scale, key_pad=kp, dense_mask=dm, causal=causal, p_drop=p_drop, seed=seed)
+        return dq, dk_, dv_
+
+    return o, lse, P, bwd
+
+
+def oracle_attn(q, k, v, keypad, causal, dense=None):
+    """fp64 oracle on (B,L,H,d) tensors -> same layout."""
+    B, Lq, H, dk = q.shape
+    Lk = k.shape[1]
+    hm = lambda t: t.double().permute(2, 0, 1, 3).reshape(H * B, t.shape[1], t.shape[3]).numpy()
+    mask = np.zeros((B, Lq, Lk), dtype=bool)
+    if keypad is not None:
+        mask |= keypad.numpy().astype(bool)[:, None, :]
+    if causal:
+        mask |= np.triu(np.ones((Lq, Lk), dtype=bool), k=1)[None]
+    if dense is not None:
+        mask |= dense.numpy().astype(bool)
+    mask_h = np.tile(mask, (H, 1, 1))
+    qh, kh, vh = hm(q), hm(k), hm(v)
+    out, p = O.sdpa_fwd(qh, kh, vh, mask_h, np.sqrt(dk))
+    back = lambda a: torch.from_numpy(a.reshape(H, B, a.shape[1], a.shape[2])).permute(1, 2, 0, 3).contiguous()
+
+    def bwd(do):
+        dq, dk_, dv_ = O.sdpa_bwd(qh, kh, vh, p, hm(do), np.sqrt(dk))
+        return back(dq), back(dk_), back(dv_)
+
+    return back(out), torch.from_numpy(p.reshape(H, B, Lq, Lk)), bwd
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", ["self_pad", "causal", "cross", "long", "dense", "d128"])
+def test_attention(L, dtype, case):
+    g = torch.Generator().manual_seed(sum(map(ord, case)))
+    B, H, Lq, Lk, dk, dv, causal, dense = {
+        "self_pad": (3, 4, 21, 21, 32, 32, False, False),
+        "causal": (2, 8, 50, 50, 64, 64, True, False),
+        "cross": (3, 2, 17, 70, 64, 64, False, False),
+        "long": (1, 2, 150, 200, 64, 64, False, False),
+        "dense": (2, 2, 9, 11, 16, 24, False, True),
+        "d128": (2, 2, 20, 33, 128, 128, False, False),
+    }[case]
+    q, k, v = rnd((B, Lq, H, dk), dtype, g), rnd((B, Lk, H, dk), dtype, g), rnd((B, Lk, H, dv), dtype, g)
+    lens = torch.randint(max(1, Lk // 2), Lk + 1, (B,), generator=g)
+    lens[0] = Lk
+    keypad = torch.arange(Lk)[None, :] >= lens[:, None]
+    dm = None
+    if dense:
+        dm = torch.rand(B, Lq, Lk, generator=g) < 0.3
+        dm[:, :, 0] = False
+    o, lse, P, bwd = run_attn(L, q, k, v, keypad, causal, dtype, dense=dm, want_p=True)
+    ro, rp, rbwd = oracle_attn(q, k, v, keypad, causal, dense=dm)
+    t = tol(dtype)
+    assert rel_err(o, ro) <= t
+    assert rel_err(P, rp) <= t
+    do = rnd(o.shape, dtype, g)
+    for got, ref in zip(bwd(do), rbwd(do)):
+        assert rel_err(got, ref) <= t
+
+
+def test_attention_golden(L):
+    gd = load_golden("attention")
+    H = int(gd["n_head"])
+    for tag, causal in (("keypad", False), ("causal", True), ("cross", False)):
+        unhead = lambda a: torch.from_numpy(a).reshape(H, -1, a.shape[1], a.shape[2]).permute(1, 2, 0, 3).contiguous()
+        q, k, v, do = (unhead(gd[f"{tag}_{n}"]) for n in ("q", "k", "v", "dout"))
+        keypad = torch.from_numpy(gd[f"{tag}_keypad"])
+        o, lse, P, bwd = run_attn(L, q, k, v, keypad, causal, torch.float32, want_p=True)
+        assert rel_err(o, unhead(gd[f"{tag}_out"])) <= F32_RTOL
+        assert rel_err(P, torch.from_numpy(gd[f"{tag}_attn"]).reshape(P.shape)) <= F32_RTOL
+        for got, name in zip(bwd(do), ("dq", "dk", "dv")):
+            assert rel_err(got, unhead(gd[f"{tag}_{name}"])) <= F32_RTOL
+
+
+def test_attention_fully_masked_row_is_nan(L):
+    q = torch.randn(1, 3, 1, 16); k = torch.randn(1, 4, 1, 16); v = torch.randn(1, 4, 1, 16)
+    keypad = torch.tensor([[True, True, True, True]])
+    o, _, _, _ = run_attn(L, q, k, v, keypad, False, torch.float32)
+    assert torch.isnan(o).all()
+
+
+def test_attention_dropout_statistics(L):
+    g = torch.Generator().manual_seed(77)
+    B, H, Lq, Lk, d = 4, 4, 48, 48, 32
+    q, k, v = rnd((B, Lq, H, d), torch.float32, g), rnd((B, Lk, H, d), torch.float32, g), rnd((B, Lk, H, d), torch.float32, g)
+    _, _, P0, _ = run_attn(L, q, k, v, None, False, torch.float32, want_p=True)
+    o1, _, P1, bwd1 = run_attn(L, q, k, v, None, False, torch.float32, p_drop=0.1, seed=123, want_p=True)
+    o2, _, P2, _ = run_attn(L, q, k, v, None, False, torch.float32, p_drop=0.1, seed=123, want_p=True)
+    assert torch.equal(P1, P2) and torch.equal(o1, o2), "same seed -> same mask"
+    kept = P1 != 0
+    rate = kept.float().mean().item()
+    assert abs(rate - 0.9) < 0.01, rate
+    assert rel_err(P1[kept], (P0 / 0.9)[kept]) <= 1e-5
+    # O must equal P_dropped @ V, and backward must use the same mask
+    Ph = P1.double().cpu()                                   # (H,B,Lq,Lk)
+    vh = v.double().permute(2, 0, 1, 3)                      # (H,B,Lk,d)
+    assert rel_err(o1, (Ph @ vh).permute(1, 2, 0, 3)) <= 1e-5
+    do = rnd(o1.shape, torch.float32, g)
+    dq, dk_, dv_ = bwd1(do)
+    assert rel_err(dv_, (Ph.transpose(2, 3) @ do.double().permute(2, 0, 1, 3)).permute(1, 2, 0, 3)) <= 1e-5
+    # dQ via autograd on the same mask
+    qa = q.double().permute(2, 0, 1, 3).requires_grad_(True)
+    ka = k.double().permute(2, 0, 1, 3).requires_grad_(True)
+    S = torch.softmax(qa @ ka.transpose(2, 3) / np.sqrt(d), -1) * (kept.cpu().double() / 0.9)
+    ((S @ vh) * do.double().permute(2, 0, 1, 3)).sum().backward()
+    assert rel_err(dq, qa.grad.permute(1, 2, 0, 3)) <= 1e-5
+    assert rel_err(dk_, ka.grad.permute(1, 2, 0, 3)) <= 1e-5
+
+
+# ------------------------------------------------------------------------------ add + LayerNorm
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("d", [32, 256, 512, 1024])
+def test_add_ln(L, dtype, d):
+    g = torch.Generator().manual_seed(d)
+    T = 203
+    x, res = rnd((T, d), dtype, g), rnd((T, d), dtype, g)
+    gamma, beta = 1 + 0.1 * torch.randn(d, generator=g), 0.1 * torch.randn(d, generator=g)
+    pad = torch.rand(T, generator=g) < 0.2
+    y, mean, rstd = L.add_ln_fwd(x.to(DEV), res.to(DEV), gamma.to(DEV), beta.to(DEV), pad.to(torch.uint8).to(DEV), 1e-5, 0.0, 0)
+    xr, rr = x.double().requires_grad_(True), res.double().requires_grad_(True)
+    gr, br = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    ref = torch.nn.functional.layer_norm(xr + rr, (d,), gr, br, 1e-5) * (~pad)[:, None]
+    assert rel_err(y, ref) <= tol(dtype)
+    assert (y[pad.to(DEV)] == 0).all()
+    dy = rnd((T, d), dtype, g)
+    ref.backward(dy.double())
+    dx, dres, dg, db = L.add_ln_bwd(dy.to(DEV), x.to(DEV), res.to(DEV), gamma.to(DEV), pad.to(torch.uint8).to(DEV), mean, rstd, 0.0, 0)
+    assert dx.data_ptr() == dres.data_ptr()
+    assert rel_err(dres, rr.grad) <= tol(dtype)
+    assert rel_err(dg, gr.grad) <= max(tol(dtype) / 4, 1e-5)
+    assert rel_err(db, br.grad) <= max(tol(dtype) / 4, 1e-5)
+
+
+def test_add_ln_dropout(L):
+    g = torch.Generator().manual_seed(8)
+    T, d, p = 512, 256, 0.1
+    x, res = rnd((T, d), torch.float32, g), rnd((T, d), torch.float32, g)
+    gamma, beta = torch.ones(d), torch.zeros(d)
+    xd, rd, gd, bd = x.to(DEV), res.to(DEV), gamma.to(DEV), beta.to(DEV)
+    y, mean, rstd = L.add_ln_fwd(xd, rd, gd, bd, None, 1e-5, p, 42)
+    dy = rnd((T, d), torch.float32, g).to(DEV)
+    dx, dres, _, _ = L.add_ln_bwd(dy, xd, rd, gd, None, mean, rstd, p, 42)
+    kept = (dx != 0).cpu()
+    assert abs(kept.float().mean().item() - (1 - p)) < 0.01
+    assert rel_err(dx.cpu()[kept], (dres.cpu() / (1 - p))[kept]) <= 1e-6
+    xr = (x * kept / (1 - p)).double()
+    ref = torch.nn.functional.layer_norm(xr + res.double(), (d,), None, None, 1e-5)
+    assert rel_err(y, ref) <= 1e-5
+
+
+# ------------------------------------------------------------------------------ embeddings
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_embed(L, dtype):
+    g = torch.Generator().manual_seed(2)
+    V, P, d, T = 50, 12, 64, 37
+    W, Pt = torch.randn(V, d, generator=g), torch.randn(P, d, generator=g)
+    seq, pos = torch.randint(0, V, (T,), generator=g), torch.randint(0, P, (T,), generator=g)
+    seq[:5] = 0
+    out = L.embed_fwd(seq.to(DEV), pos.to(DEV), W.to(DEV), Pt.to(DEV), dtype)
+    assert rel_err(out, W[seq] + Pt[pos]) <= (1e-7 if dtype == torch.float32 else 1e-2)
+    dout = rnd((T, d), dtype, g)
+    dW = torch.zeros(V, d, device=DEV)
+    L.embed_bwd(seq.to(DEV), dout.to(DEV), dW, 0)
+    ref = torch.zeros(V, d, dtype=torch.float64).index_add_(0, seq, dout.double())
+    ref[0] = 0
+    assert rel_err(dW, ref) <= 1e-6
+
+
+# ------------------------------------------------------------------------------ loss
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("V", [23, 4096, 35000])
+def test_xent(L, dtype, V):
+    g = torch.Generator().manual_seed(V)
+    T = 40
+    logits = rnd((T, V), dtype, g, 3.0)
+    gold = torch.randint(1, V, (T,), generator=g)
+    gold[::7] = 0
+    for eps, scale in ((0.1, 1.0), (0.0, 1.0), (0.1, 0.125)):
+        ld = logits.to(DEV)
+        dl = torch.empty_like(ld)
+        stats = torch.zeros(3, dtype=torch.float64, device=DEV)
+        L.xent_fwd_bwd(ld, gold.to(DEV), dl, stats, scale, eps, 0)
+        loss, dpred, nc = O.ls_xent(logits.double().numpy() * scale, gold.numpy(), eps > 0, eps if eps > 0 else 0.1)
+        s = stats.cpu().numpy()
+        assert abs(s[0] - loss) <= (1e-5 if dtype == torch.float32 else 1e-3) * abs(loss)
+        assert int(s[1]) == nc and int(s[2]) == int((gold != 0).sum())
+        assert rel_err(dl, torch.from_numpy(dpred * scale)) <= tol(dtype)
+    # in place (dlogits aliases logits) gives the same bits as out of place
+    ld, ld2 = logits.to(DEV), logits.to(DEV)
+    dl = torch.empty_like(ld)
+    stats = torch.zeros(3, dtype=torch.float64, device=DEV)
+    L.xent_fwd_bwd(ld, gold.to(DEV), dl, stats, 1.0, 0.1, 0)
+    L.xent_fwd_bwd(ld2, gold.to(DEV), ld2, stats, 1.0, 0.1, 0)
+    assert torch.equal(ld2, dl)
+
+
+def test_xent_golden(L):
+    gd = load_golden("loss")
+    pred, gold = torch.from_numpy(gd["pred"]).to(DEV), torch.from_numpy(gd["gold"]).to(DEV)
+    for s, eps in (("ls", 0.1), ("ce", 0.0)):
+        dl = torch.empty_like(pred)
+        stats = torch.zeros(3, dtype=torch.float64, device=DEV)
+        L.xent_fwd_bwd(pred, gold, dl, stats, 1.0, eps, 0)
+        assert abs(stats[0].item() - float(gd[f"loss_{s}"])) <= 1e-5 * abs(float(gd[f"loss_{s}"]))
+        assert int(stats[1].item()) == int(gd[f"ncorrect_{s}"])
+        assert rel_err(dl, torch.from_numpy(gd[f"dpred_{s}"])) <= 1e-5
+
+
+# ------------------------------------------------------------------------------ Adam
+def make_tables(tensors_by_key):
+    out = {}
+    for k, ts in tensors_by_key.items():
+        if ts is None:
+            out[k] = None
+        elif k == "n":
+            out[k] = torch.tensor(ts, dtype=torch.int64, device=DEV)
+        else:
+            out[k] = torch.tensor([t.data_ptr() for t in ts], dtype=torch.int64, device=DEV)
+    return out
+
+
+def test_adam_golden(L):
+    gd = load_golden("optim")
+    d_model, warm = int(gd["d_model"]), int(gd["n_warmup"])
+    p = [torch.from_numpy(gd["p1_0"]).to(DEV), torch.from_numpy(gd["p2_0"]).to(DEV)]
+    m = [torch.zeros_like(t) for t in p]
+    v = [torch.zeros_like(t) for t in p]
+    gbuf = [torch.zeros_like(t) for t in p]
+    b = [torch.zeros(t.shape, dtype=torch.bfloat16, device=DEV) for t in p]
+    tables = make_tables({"p": p, "g": gbuf, "m": m, "v": v, "b": b, "n": [t.numel() for t in p]})
+    for step in range(1, 7):
+        gbuf[0].copy_(torch.from_numpy(gd[f"g1_{step}"]))
+        gbuf[1].copy_(torch.from_numpy(gd[f"g2_{step}"]))
+        lr = O.noam_lr(step, d_model, warm)
+        L.adam_multi(tables, 2, max(t.numel() for t in p), lr, 0.9, 0.98, 1e-9, step)
+        assert rel_err(p[0], torch.from_numpy(gd[f"p1_{step}"])) <= 1e-6
+        assert rel_err(p[1], torch.from_numpy(gd[f"p2_{step}"])) <= 1e-6
+        assert torch.equal(b[0], p[0].to(torch.bfloat16)) and torch.equal(b[1], p[1].to(torch.bfloat16))
+
+
+def test_cast_and_convert(L):
+    a = [torch.randn(1000, device=DEV), torch.randn(3, 5, device=DEV)]
+    b = [torch.empty(t.shape, dtype=torch.bfloat16, device=DEV) for t in a]
+    t = make_tables({"s": a, "d": b, "n": [x.numel() for x in a]})
+    L.cast_multi(t["s"], t["d"], t["n"], 2, 1000)
+    for x, y in zip(a, b):
+        assert torch.equal(y, x.to(torch.bfloat16))
+    out = L.convert(b[0], torch.empty(1000, device=DEV))
+    assert torch.equal(out, b[0].float())
+
+
+# ------------------------------------------------------------------------------ decode
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_decode_attn(L, dtype):
+    g = torch.Generator().manual_seed(4)
+    R, H, Lmax, dk, dv = 7, 4, 90, 64, 64
+    q = rnd((R, H * dk), dtype, g)
+    Kc, Vc = rnd((R, Lmax, H * dk), dtype, g), rnd((R, Lmax, H * dv), dtype, g)
+    lens = torch.randint(1, Lmax + 1, (R,), generator=g).to(torch.int32)
+    lens[0] = Lmax
+    keypad = torch.rand(R, Lmax, generator=g) < 0.2
+    keypad[:, 0] = False
+    out = torch.empty((R, H * dv), dtype=dtype, device=DEV)
+    L.decode_attn(q.to(DEV), Kc.to(DEV), Vc.to(DEV), out, R, H, Lmax, Lmax, dk, dv, H * dk, H * dv, 1 / np.sqrt(dk),
+                  kv_len=lens.to(DEV), key_pad=keypad.to(torch.uint8).to(DEV))
+    mask = keypad | (torch.arange(Lmax)[None] >= lens[:, None])
+    ro, _, _ = oracle_attn(q.view(R, 1, H, dk), Kc.view(R, Lmax, H, dk), Vc.view(R, Lmax, H, dv), mask, False)
+    assert rel_err(out.view(R, 1, H, dv), ro) <= tol(dtype)
+
+
+@pytest.mark.parametrize("bm", [1, 3, 5, 8])
+def test_beam_topk(L, bm):
+    g = torch.Generator().manual_seed(bm)
+    for V in (24, 4096, 35000):
+        n_sent = 6
+        logits = torch.randn(n_sent * bm, V, generator=g) * 2
+        logits[1, 7] = logits[1, 3]  # an exact tie inside a row
+        scores = -torch.rand(n_sent, bm, generator=g) * 5
+        for first in (True, False):
+            so, prev, tok = L.beam_topk(logits.to(DEV), scores.to(DEV), n_sent, bm, first)
+            lp = torch.log_softmax(logits, 1).view(n_sent, bm, V)
+            for s in range(n_sent):
+                flat = (lp[s, 0] if first else (lp[s] + scores[s][:, None]).reshape(-1)).numpy()
+                best, ids = O.stable_topk(flat, bm)
+                assert (prev[s].cpu().numpy() == ids // V).all(), (V, s, first)
+                assert (tok[s].cpu().numpy() == ids % V).all(), (V, s, first)
+                np.testing.assert_allclose(so[s].cpu().numpy(), best, rtol=1e-5, atol=1e-5)
+
+
+def test_gather_rows(L):
+    g = torch.Generator().manual_seed(6)
+    for dtype, elems in ((torch.float32, 96), (torch.bfloat16, 100), (torch.bfloat16, 64)):
+        src = rnd((9, 128), dtype, g).to(DEV)
+        idx = torch.tensor([3, 3, 0, 8, 1], dtype=torch.int32, device=DEV)
+        dst = torch.zeros((5, 128), dtype=dtype, device=DEV)
+        L.gather_rows(src, dst, idx, 5, elems, 128, 128)
+        assert torch.equal(dst[:, :elems], src[idx.long(), :elems])
+        assert (dst[:, elems:] == 0).all()
