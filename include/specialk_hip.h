@@ -171,14 +171,18 @@ int skhip_convert(const void* src, void* dst, int64_t n, int src_dtype, int dst_
 /* Single-query attention over a KV cache (incremental replacement for re-running the
  * decoder on the whole prefix, Translator.py:130-140).  q [R][h*dk]; K/V cache
  * [R][Lmax][h*dk|h*dv] of which the first kv_len[r] (or `len` if kv_len NULL) entries are
- * valid; key_pad optional [R][Lmax].  out [R][h*dv].                                       */
+ * valid; key_pad optional [R][Lmax].  out [R][h*dv].
+ * kv_row_div >= 1: query row r reads cache row r / kv_row_div (and key_pad / kv_len row
+ * r / kv_row_div), so the beams of one sentence share a single encoder-side K/V copy.       */
 int skhip_decode_attn(const void* q, const void* Kc, const void* Vc, void* out,
                       const int32_t* kv_len, const uint8_t* key_pad, int R, int n_head, int len,
                       int Lmax, int dk, int dv, int64_t ldq, int64_t ldo, float scale,
-                      int dtype, void* stream);
+                      int kv_row_div, int dtype, void* stream);
 
 /* log_softmax over V + beam expansion + top-`bm` per sentence.
  * logits [n_sent*bm][V] fp32 (ld = V).  scores_in [n_sent][bm] fp32.
+ * normalize != 0: rows are raw generator outputs and log_softmax is applied here;
+ * normalize == 0: rows already hold log-probabilities (the argument of Beam.advance).
  * first_step != 0: only beam 0 of each sentence is considered (Beam.py:51-54).
  * Outputs per sentence, sorted by descending score, ties to the lower flat index:
  * scores_out [n_sent][bm], prev_out [n_sent][bm] (source beam = flat_id / V),
@@ -187,7 +191,7 @@ int skhip_decode_attn(const void* q, const void* Kc, const void* Vc, void* out,
 int64_t skhip_beam_topk_ws_bytes(int n_sent, int bm, int64_t V);
 int skhip_beam_topk(const float* logits, const float* scores_in, float* scores_out,
                     int32_t* prev_out, int32_t* tok_out, void* ws, int n_sent, int bm, int64_t V,
-                    int first_step, void* stream);
+                    int first_step, int normalize, void* stream);
 
 /* Reorder a cache after a beam step: dst[r] = src[src_row[r]] for rows of `row_elems`
  * elements (replaces re-building dec_seq from back-pointers every step, Beam.py:90-110,

@@ -59,8 +59,8 @@ def load():
     lib.skhip_adam_multi.argtypes = [c_p] * 6 + [c_int, c_i64, c_f32, c_f32, c_f32, c_f32, c_int, c_f32, c_p]
     lib.skhip_cast_multi.argtypes = [c_p] * 3 + [c_int, c_i64, c_p]
     lib.skhip_convert.argtypes = [c_p, c_p, c_i64, c_int, c_int, c_p]
-    lib.skhip_decode_attn.argtypes = [c_p] * 6 + [c_int] * 6 + [c_i64, c_i64, c_f32, c_int, c_p]
-    lib.skhip_beam_topk.argtypes = [c_p] * 6 + [c_int, c_int, c_i64, c_int, c_p]
+    lib.skhip_decode_attn.argtypes = [c_p] * 6 + [c_int] * 6 + [c_i64, c_i64, c_f32, c_int, c_int, c_p]
+    lib.skhip_beam_topk.argtypes = [c_p] * 6 + [c_int, c_int, c_i64, c_int, c_int, c_p]
     lib.skhip_gather_rows.argtypes = [c_p] * 3 + [c_i64] * 4 + [c_int, c_p]
     for name in EXPORTS:
         getattr(lib, name)  # AttributeError here means header and library disagree
@@ -246,14 +246,15 @@ def convert(src, dst):
 
 
 # --------------------------------------------------------------------------- decode
-def decode_attn(q, Kc, Vc, out, R, H, length, Lmax, dk, dv, ldq, ldo, scale, kv_len=None, key_pad=None):
+def decode_attn(q, Kc, Vc, out, R, H, length, Lmax, dk, dv, ldq, ldo, scale, kv_len=None, key_pad=None,
+                kv_row_div=1):
     lib = load()
     rc = lib.skhip_decode_attn(_ptr(q), _ptr(Kc), _ptr(Vc), _ptr(out), _ptr(kv_len), _ptr(key_pad), R, H, length,
-                               Lmax, dk, dv, ldq, ldo, float(scale), dcode(q.dtype), _stream())
+                               Lmax, dk, dv, ldq, ldo, float(scale), int(kv_row_div), dcode(q.dtype), _stream())
     _check(rc, "skhip_decode_attn")
 
 
-def beam_topk(logits, scores_in, n_sent, bm, first_step):
+def beam_topk(logits, scores_in, n_sent, bm, first_step, normalize=True):
     lib = load()
     V = logits.shape[-1]
     dev = logits.device
@@ -262,7 +263,7 @@ def beam_topk(logits, scores_in, n_sent, bm, first_step):
     tok = torch.empty((n_sent, bm), dtype=torch.int32, device=dev)
     ws = workspace(int(lib.skhip_beam_topk_ws_bytes(n_sent, bm, V)))
     rc = lib.skhip_beam_topk(_ptr(logits), _ptr(scores_in), _ptr(scores_out), _ptr(prev), _ptr(tok), _ptr(ws),
-                             n_sent, bm, V, int(first_step), _stream())
+                             n_sent, bm, V, int(first_step), int(normalize), _stream())
     _check(rc, "skhip_beam_topk")
     return scores_out, prev, tok
 

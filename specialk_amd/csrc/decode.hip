@@ -19,24 +19,26 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const T* __restrict__ 
                                                           const T* __restrict__ Vc, T* __restrict__ out,
                                                           const int32_t* __restrict__ kv_len,
                                                           const uint8_t* __restrict__ key_pad, int R, int H, int len,
-                                                          int Lmax, int dk, int dv, int64_t ldq, int64_t ldo, float scale) {
+                                                          int Lmax, int dk, int dv, int64_t ldq, int64_t ldo, float scale,
+                                                          int kv_row_div) {
   __shared__ float qs[4][128];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int pair = blockIdx.x * 4 + wave;
   if (pair >= R * H) return;  // wave-uniform
   const int r = pair / H, h = pair - r * H;
-  const int n = kv_len ? kv_len[r] : len;
+  const int kr_row = r / kv_row_div;
+  const int n = kv_len ? kv_len[kr_row] : len;
   for (int c = lane; c < dk; c += 64) qs[wave][c] = Cvt<T>::to_f32(q[(int64_t)r * ldq + h * dk + c]) * scale;
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __builtin_amdgcn_wave_barrier();
-  const T* Kr = Kc + (int64_t)r * Lmax * H * dk + h * dk;
-  const T* Vr = Vc + (int64_t)r * Lmax * H * dv + h * dv;
+  const T* Kr = Kc + (int64_t)kr_row * Lmax * H * dk + h * dk;
+  const T* Vr = Vc + (int64_t)kr_row * Lmax * H * dv + h * dv;
   float m = -INFINITY, l = 0.f, acc0 = 0.f, acc1 = 0.f;
   const int c0 = lane < dv ? lane : 0, c1 = lane + 64 < dv ? lane + 64 : 0;
   for (int j0 = 0; j0 < n; j0 += 64) {
     const int j = j0 + lane;
     float s = -INFINITY;
-    if (j < n && !(key_pad && key_pad[(int64_t)r * Lmax + j])) {
+    if (j < n && !(key_pad && key_pad[(int64_t)kr_row * Lmax + j])) {
       const T* kr = Kr + (int64_t)j * H * dk;
       float a = 0.f;
       for (int c = 0; c < dk; ++c) a += qs[wave][c] * Cvt<T>::to_f32(kr[c]);
@@ -81,11 +83,10 @@ template <int KC>
 __global__ __launch_bounds__(256) void beam_row_topk_kernel(const float* __restrict__ logits,
                                                             const float* __restrict__ scores_in,
                                                             float* __restrict__ cand_val, int32_t* __restrict__ cand_idx,
-                                                            int bm, int64_t V, int first_step) {
+                                                            int bm, int64_t V, int first_step, int normalize) {
   __shared__ float s_red[4];
   __shared__ float s_val[4];
   __shared__ int s_idx[4];
-  __shared__ float s_best_v;
   __shared__ int s_best_i;
   const int row = blockIdx.x, beam = row % bm;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -120,13 +121,18 @@ __global__ __launch_bounds__(256) void beam_row_topk_kernel(const float* __restr
   __syncthreads();
   mx = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
   __syncthreads();
-  float se = 0.f;
-  for (int64_t c = threadIdx.x; c < V; c += 256) se += expf(x[c] - mx);
-  se = wave_sum(se);
-  if (lane == 0) s_red[wave] = se;
-  __syncthreads();
-  se = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
-  const float logse = logf(se);
+  float logse = 0.f;
+  if (normalize) {
+    float se = 0.f;
+    for (int64_t c = threadIdx.x; c < V; c += 256) se += expf(x[c] - mx);
+    se = wave_sum(se);
+    if (lane == 0) s_red[wave] = se;
+    __syncthreads();
+    se = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+    logse = logf(se);
+  } else {
+    mx = 0.f;
+  }
   const float sc = first_step ? 0.f : scores_in[row];
   // bm rounds: block-wide best of the per-thread heads; the winner pops its head.
   for (int round = 0; round < bm; ++round) {
@@ -139,7 +145,7 @@ __global__ __launch_bounds__(256) void beam_row_topk_kernel(const float* __restr
       float bv = s_val[0]; int bi = s_idx[0];
 #pragma unroll
       for (int w = 1; w < 4; ++w) if (better(s_val[w], s_idx[w], bv, bi)) { bv = s_val[w]; bi = s_idx[w]; }
-      s_best_v = bv; s_best_i = bi;
+      s_best_i = bi;
       float lp = (bv - mx) - logse;
       cv[round] = first_step ? lp : lp + sc;
       ci[round] = bi;
@@ -220,9 +226,10 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const char* __restrict
 
 extern "C" int skhip_decode_attn(const void* q, const void* Kc, const void* Vc, void* out, const int32_t* kv_len,
                                  const uint8_t* key_pad, int R, int n_head, int len, int Lmax, int dk, int dv, int64_t ldq,
-                                 int64_t ldo, float scale, int dtype, void* stream_) {
+                                 int64_t ldo, float scale, int kv_row_div, int dtype, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   SK_CHECK_ARG(dtype == SK_F32 || dtype == SK_BF16, "skhip_decode_attn: bad dtype");
+  SK_CHECK_ARG(kv_row_div >= 1, "skhip_decode_attn: kv_row_div=%d", kv_row_div);
   SK_CHECK_ARG(R >= 0 && n_head > 0 && dk > 0 && dv > 0 && dk <= 128 && dv <= 128, "skhip_decode_attn: bad shape");
   SK_CHECK_ARG(len >= 0 && len <= Lmax, "skhip_decode_attn: len=%d exceeds Lmax=%d", len, Lmax);
   if (R == 0) return SK_OK;
@@ -231,10 +238,10 @@ extern "C" int skhip_decode_attn(const void* q, const void* Kc, const void* Vc, 
   if (dtype == SK_BF16)
     hipLaunchKernelGGL((decode_attn_kernel<bf16_t>), dim3(blocks), dim3(256), 0, stream, (const bf16_t*)q,
                        (const bf16_t*)Kc, (const bf16_t*)Vc, (bf16_t*)out, kv_len, key_pad, R, n_head, len, Lmax, dk, dv,
-                       ldq, ldo, scale);
+                       ldq, ldo, scale, kv_row_div);
   else
     hipLaunchKernelGGL((decode_attn_kernel<float>), dim3(blocks), dim3(256), 0, stream, (const float*)q, (const float*)Kc,
-                       (const float*)Vc, (float*)out, kv_len, key_pad, R, n_head, len, Lmax, dk, dv, ldq, ldo, scale);
+                       (const float*)Vc, (float*)out, kv_len, key_pad, R, n_head, len, Lmax, dk, dv, ldq, ldo, scale, kv_row_div);
   SK_CHECK_LAUNCH("skhip_decode_attn");
   return SK_OK;
 }
@@ -245,7 +252,8 @@ extern "C" int64_t skhip_beam_topk_ws_bytes(int n_sent, int bm, int64_t V) {
 }
 
 extern "C" int skhip_beam_topk(const float* logits, const float* scores_in, float* scores_out, int32_t* prev_out,
-                               int32_t* tok_out, void* ws, int n_sent, int bm, int64_t V, int first_step, void* stream_) {
+                               int32_t* tok_out, void* ws, int n_sent, int bm, int64_t V, int first_step, int normalize,
+                               void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   SK_CHECK_ARG(bm >= 1 && bm <= 16, "skhip_beam_topk: beam size %d not in 1..16", bm);
   SK_CHECK_ARG(V >= bm && V < (1ll << 31), "skhip_beam_topk: V=%lld", (long long)V);
@@ -254,7 +262,7 @@ extern "C" int skhip_beam_topk(const float* logits, const float* scores_in, floa
   float* cv = (float*)ws;
   int32_t* ci = (int32_t*)(cv + (int64_t)n_sent * bm * bm);
   dim3 grid((unsigned)(n_sent * bm));
-#define BEAM_A(KC) hipLaunchKernelGGL((beam_row_topk_kernel<KC>), grid, dim3(256), 0, stream, logits, scores_in, cv, ci, bm, V, first_step)
+#define BEAM_A(KC) hipLaunchKernelGGL((beam_row_topk_kernel<KC>), grid, dim3(256), 0, stream, logits, scores_in, cv, ci, bm, V, first_step, normalize)
   if (bm <= 1) BEAM_A(1);
   else if (bm <= 2) BEAM_A(2);
   else if (bm <= 4) BEAM_A(4);

@@ -1,0 +1,162 @@
+"""Incremental beam-search decoding with a KV cache, beams resident on the GPU.
+
+Computes exactly what Translator.translate_batch of the reference computes
+(lib/transformer/Translator.py:55-226 with Beam, lib/transformer/Beam.py:14-110) but:
+  * each step runs the decoder on the newest position only; keys/values of earlier positions
+    live in per-layer caches that are re-ordered by the beams' back-pointers
+    (the reference re-runs the whole prefix, O(t^2));
+  * encoder-side keys/values are projected once per sentence and shared by its beams;
+  * log-softmax, score accumulation and top-k of ALL sentences are two kernel launches
+    (the reference loops over Python Beam objects and syncs with .item());
+  * the host reads one flag per step (all sentences finished?) and the token history once at
+    the end.
+Reference quirks kept: the generator is applied without x_logit_scale (Translator.py:137);
+a sentence ends when its TOP beam emits EOS, other beams keep extending past EOS; no length
+penalty; step 1 only expands beam 0.
+"""
+import numpy as np
+import torch
+
+from . import _lib as L
+from . import ops
+from .core import constants as Constants
+
+
+class BeamDecoder:
+    def __init__(self, model, beam_size, max_token_seq_len):
+        self.model = model
+        self.bm = int(beam_size)
+        self.max_len = int(max_token_seq_len)
+
+    def _w(self, p, dtype):
+        w = ops.compute_weight(p, dtype)
+        return w.reshape(w.shape[0], -1)
+
+    @torch.no_grad()
+    def run(self, src_seq, src_pos, n_best=1):
+        model, bm, Tmax = self.model, self.bm, self.max_len
+        dec = model.decoder
+        dt = dec.compute_dtype
+        dev = src_seq.device
+        n, Ls = src_seq.shape
+        R = n * bm
+        layers = list(dec.layer_stack)
+        NL = len(layers)
+        mha0 = layers[0].slf_attn
+        H, dk, dv = mha0.n_head, mha0.d_k, mha0.d_v
+        d = dec.tgt_word_emb.weight.shape[1]
+        scale = 1.0 / float(mha0.attention.temperature)
+        n_pos = dec.position_enc.weight.shape[0]
+        if Tmax >= n_pos:
+            raise IndexError(f"max_token_seq_len={Tmax} needs a position table of {Tmax + 1} rows, have {n_pos}")
+
+        was_training = model.training
+        model.eval()
+        enc_out, *_ = model.encoder(src_seq, src_pos)
+        enc2d = enc_out.reshape(n * Ls, d)
+        src_key_pad = src_seq.eq(Constants.PAD).to(torch.uint8).contiguous()
+
+        # encoder-side K/V: once per sentence, shared by its beams
+        crossK = torch.empty((NL, n, Ls, H * dk), dtype=dt, device=dev)
+        crossV = torch.empty((NL, n, Ls, H * dv), dtype=dt, device=dev)
+        for li, layer in enumerate(layers):
+            a = layer.enc_attn
+            L.gemm(L.GEMM_NT, enc2d, self._w(a.w_ks.weight, dt), n * Ls, H * dk, d, d, d, out=crossK[li], ldc=H * dk,
+                   bias=a.w_ks.bias.detach())
+            L.gemm(L.GEMM_NT, enc2d, self._w(a.w_vs.weight, dt), n * Ls, H * dv, d, d, d, out=crossV[li], ldc=H * dv,
+                   bias=a.w_vs.bias.detach())
+
+        # self-attention caches, double buffered for the beam re-ordering gather; the time axis is
+        # rounded up to 16 so that a row of the PAD-token bitmap can be gathered as 4-byte words
+        Tc = (Tmax + 15) // 16 * 16
+        Kc = [torch.zeros((NL, R, Tc, H * dk), dtype=dt, device=dev) for _ in range(2)]
+        Vc = [torch.zeros((NL, R, Tc, H * dv), dtype=dt, device=dev) for _ in range(2)]
+        pad_hist = [torch.zeros((R, Tc), dtype=torch.uint8, device=dev) for _ in range(2)]
+        cur = 0
+
+        scores = torch.zeros((n, bm), dtype=torch.float32, device=dev)
+        ys = torch.zeros((Tmax + 1, n, bm), dtype=torch.int32, device=dev)
+        ks = torch.zeros((Tmax, n, bm), dtype=torch.int32, device=dev)
+        done = torch.zeros(n, dtype=torch.bool, device=dev)
+        length = torch.full((n,), Tmax, dtype=torch.int32, device=dev)
+        tok = torch.full((R,), Constants.SOS, dtype=torch.int64, device=dev)
+        sent_base = (torch.arange(n, device=dev, dtype=torch.int32) * bm)[:, None]
+        layer_off = (torch.arange(NL, device=dev, dtype=torch.int32) * R)[:, None]
+        gen_w = self._w(model.generator.weight, dt)
+        V = gen_w.shape[0]
+        word_emb, pos_tab = dec.tgt_word_emb.weight.detach(), dec.position_enc.weight.detach()
+
+        def proj(x, lin, out=None, ldc=None, relu=False):
+            w = self._w(lin.weight, dt)
+            return L.gemm(L.GEMM_NT, x, w, R, w.shape[0], w.shape[1], x.stride(0), w.shape[1], out=out, ldc=ldc,
+                          bias=lin.bias.detach(), epilogue=L.EPI_RELU if relu else 0)
+
+        def add_ln(o, x, ln, row_pad):
+            y, _, _ = L.add_ln_fwd(o, x, ln.weight.detach(), ln.bias.detach(), row_pad, ln.eps, 0.0, 0)
+            return y
+
+        steps = 0
+        for t in range(1, Tmax + 1):
+            steps = t
+            pos = torch.full((R,), t, dtype=torch.int64, device=dev)
+            row_pad = tok.eq(Constants.PAD).to(torch.uint8)
+            pad_hist[cur][:, t - 1] = row_pad
+            x = L.embed_fwd(tok, pos, word_emb, pos_tab, dt)
+            for li, layer in enumerate(layers):
+                a = layer.slf_attn
+                q = proj(x, a.w_qs)
+                proj(x, a.w_ks, out=Kc[cur][li, :, t - 1], ldc=Tc * H * dk)
+                proj(x, a.w_vs, out=Vc[cur][li, :, t - 1], ldc=Tc * H * dv)
+                att = torch.empty((R, H * dv), dtype=dt, device=dev)
+                L.decode_attn(q, Kc[cur][li], Vc[cur][li], att, R, H, t, Tc, dk, dv, H * dk, H * dv, scale,
+                              key_pad=pad_hist[cur])
+                x = add_ln(proj(att, a.fc), x, a.layer_norm, row_pad)
+                a = layer.enc_attn
+                q = proj(x, a.w_qs)
+                L.decode_attn(q, crossK[li], crossV[li], att, R, H, Ls, Ls, dk, dv, H * dk, H * dv, scale,
+                              key_pad=src_key_pad, kv_row_div=bm)
+                x = add_ln(proj(att, a.fc), x, a.layer_norm, row_pad)
+                f = layer.pos_ffn
+                hbuf = proj(x, f.w_1, relu=True)
+                x = add_ln(proj(hbuf, f.w_2), x, f.layer_norm, row_pad)
+            logits = L.gemm(L.GEMM_NT, x, gen_w, R, V, d, d, d, out_dtype=torch.float32)
+            new_scores, prev, new_tok = L.beam_topk(logits, scores, n, bm, first_step=(t == 1))
+            # finished sentences keep their final beam state (their Beam is no longer advanced)
+            keep = done[:, None]
+            scores = torch.where(keep, scores, new_scores)
+            ks[t - 1] = prev
+            ys[t] = new_tok
+            newly = (~done) & new_tok[:, 0].eq(Constants.EOS)
+            length = torch.where(newly, torch.full_like(length, t), length)
+            done = done | newly
+            if bool(done.all()):  # the one host sync of the step
+                break
+            # re-order caches by back-pointer: new row (s, b) <- old row (s, prev[s, b])
+            src_row = (sent_base + prev).reshape(-1)
+            all_rows = (layer_off + src_row[None, :]).reshape(-1).contiguous()
+            nxt = cur ^ 1
+            L.gather_rows(Kc[cur], Kc[nxt], all_rows, NL * R, t * H * dk, Tc * H * dk, Tc * H * dk)
+            L.gather_rows(Vc[cur], Vc[nxt], all_rows, NL * R, t * H * dv, Tc * H * dv, Tc * H * dv)
+            L.gather_rows(pad_hist[cur].view(torch.float32), pad_hist[nxt].view(torch.float32), src_row.contiguous(),
+                          R, Tc // 4, Tc // 4, Tc // 4)
+            cur = nxt
+            tok = new_tok.reshape(-1).to(torch.int64)
+        if was_training:
+            model.train()
+
+        # hypotheses: walk the back-pointers on the host (Beam.get_hypothesis, Beam.py:103-110)
+        ys_h, ks_h = ys[: steps + 1].cpu().numpy(), ks[:steps].cpu().numpy()
+        len_h, scores_h = length.cpu().numpy(), scores
+        all_hyp, all_scores = [], []
+        for s in range(n):
+            T_s = int(min(len_h[s], steps))
+            hyps = []
+            for k0 in range(min(n_best, bm)):
+                k, hyp = k0, []
+                for j in range(T_s - 1, -1, -1):
+                    hyp.append(int(ys_h[j + 1, s, k]))
+                    k = int(ks_h[j, s, k])
+                hyps.append(hyp[::-1])
+            all_hyp.append(hyps)
+            all_scores.append(scores_h[s, :n_best])
+        return all_hyp, all_scores
