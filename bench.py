@@ -1,0 +1,284 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Transformer-base training step throughput (train target tokens/sec).
+
+  python bench.py --gpus N --steps K --warmup W          (N=1)
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one full optimiser step of the hot path on one synthetic batch per GPU:
+zero_grad, encoder-decoder forward, label-smoothed loss, backward, (N>1: bucketed RCCL SUM
+all-reduce of gradients overlapped with backward), fused Adam with the Noam schedule, dropout
+on as in the reference's training mode.  Workload (BASELINE.json configs[1]): 6+6 layers,
+d_model 512, 8 heads x 64, FFN 2048, vocab 35000 untied, bf16 compute with fp32 master weights,
+640 sentences per GPU with lengths U[28,50] (+SOS/EOS) = ~25k non-pad target tokens, inputs
+resident in HBM before the timed region.  Weak scaling: per-GPU batch fixed.
+
+Prints ONE JSON line on rank 0 with the contract fields plus
+  roofline:     bf16 MFMA GEMM kernel, algorithmic FLOPs (non-pad rows only) / HIP-event time
+  cpu_baseline: the numpy oracle (a port of the reference's algorithm) timed on host cores on
+                a bounded sample of the same workload (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CONFIGS = {
+    # name: (n_layers, d_model, n_head, d_k, d_inner, vocab, tied, batch, len_lo, len_hi)
+    "cfg2": dict(n_layers=6, d_model=512, n_head=8, d_k=64, d_inner=2048, vocab=35000, tied=False, batch=640,
+                 lo=28, hi=50, desc="Transformer-base 6+6 d512 FFN2048 V35000, 640 sent/GPU (~25k tgt tokens)"),
+    "cfg1": dict(n_layers=2, d_model=256, n_head=8, d_k=32, d_inner=1024, vocab=4096, tied=False, batch=64,
+                 lo=6, hi=24, desc="2-layer d256 8-head V4096, 64 sentences (Multi30k-shaped)"),
+    "cfg4": dict(n_layers=6, d_model=1024, n_head=16, d_k=64, d_inner=4096, vocab=44544, tied=True, batch=320,
+                 lo=28, hi=50, desc="Transformer-big 6+6 d1024 16-head FFN4096 V44544 tied, 320 sent/GPU"),
+}
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16, MI355X
+PAD, SOS, EOS = 0, 2, 3
+
+
+def make_batch(g, n, lo, hi, vocab):
+    lens = torch.randint(lo, hi + 1, (n,), generator=g)
+    L = int(lens.max()) + 2
+    seq = torch.zeros(n, L, dtype=torch.long)
+    ids = torch.randint(5, vocab, (n, L), generator=g)
+    ar = torch.arange(L)[None, :]
+    body = (ar >= 1) & (ar <= lens[:, None])
+    seq[body] = ids[body]
+    seq[:, 0] = SOS
+    seq[torch.arange(n), lens + 1] = EOS
+    pos = torch.where(seq != PAD, ar + 1, torch.zeros_like(seq))
+    return seq, pos
+
+
+def build(cfg, dtype, device):
+    from specialk_amd.lib.transformer.Models import Transformer
+    from specialk_amd.lib.transformer.Optim import ScheduledOptim
+    from specialk_amd.optim import FusedAdam
+    torch.manual_seed(1234)
+    m = Transformer(cfg["vocab"], cfg["vocab"], cfg["hi"] + 3, d_word_vec=cfg["d_model"], d_model=cfg["d_model"],
+                    d_inner=cfg["d_inner"], n_layers=cfg["n_layers"], n_head=cfg["n_head"], d_k=cfg["d_k"],
+                    d_v=cfg["d_k"], dropout=0.1, tgt_emb_prj_weight_sharing=cfg["tied"],
+                    emb_src_tgt_weight_sharing=cfg["tied"])
+    for p in m.parameters():  # TransformerModel.initiate (lib/TransformerModel.py:73-75)
+        if p.dim() > 1:
+            torch.nn.init.xavier_uniform_(p)
+    m = m.to(device).set_compute_dtype(dtype)
+    m.encoder.check_ids = m.decoder.check_ids = False  # synthetic ids are valid by construction
+    m.train()
+    opt = ScheduledOptim(FusedAdam(filter(lambda x: x.requires_grad, m.parameters()), betas=(0.9, 0.98), eps=1e-09),
+                         cfg["d_model"], 4000)
+    return m, opt
+
+
+def train_step(m, opt, batch, reducer):
+    from specialk_amd import ops
+    src_seq, src_pos, tgt_seq, tgt_pos = batch
+    if reducer is not None:
+        reducer.zero_grad()
+    else:
+        opt.zero_grad()
+    pred = m(src_seq, src_pos, tgt_seq, tgt_pos)
+    loss, stats = ops.xent(pred.view(-1, pred.size(2)), tgt_seq[:, 1:], True, unit_grad=True)
+    loss.backward()
+    if reducer is not None:
+        reducer.finish()
+    opt.step_and_update_lr()
+    return stats
+
+
+def gemm_roofline(m, opt, batch, steps):
+    """Instrumented extra steps (after the timed region, same process, same data): every bf16
+    GEMM launch is bracketed by HIP events on the launch stream.  Algorithmic FLOPs credit only
+    non-pad rows (padding work earns no credit)."""
+    from specialk_amd import _lib as L
+    src_seq, _, tgt_seq, _ = batch
+    Ts, Tt = src_seq.numel(), tgt_seq[:, :-1].numel()
+    frac = {Ts: float((src_seq != PAD).sum()) / Ts}
+    ft = float((tgt_seq[:, :-1] != PAD).sum()) / Tt
+    frac[Tt] = ft if Tt not in frac else 0.5 * (ft + frac[Tt])
+    records = []
+    orig = L.gemm
+
+    def timed(layout, A, B, M, N, K, *a, **kw):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = orig(layout, A, B, M, N, K, *a, **kw)
+        e1.record()
+        f = frac.get(M, frac.get(K, 1.0))
+        records.append((e0, e1, 2.0 * M * N * K * f, A.dtype))
+        return out
+
+    L.gemm = timed
+    try:
+        for _ in range(steps):
+            train_step(m, opt, batch, None)
+        torch.cuda.synchronize()
+    finally:
+        L.gemm = orig
+    ms = sum(e0.elapsed_time(e1) for e0, e1, _, _ in records)
+    flops = sum(f for _, _, f, _ in records)
+    n = len(records)
+    return dict(bound="mfma", achieved=round(flops / (ms * 1e-3) / 1e12, 2), peak=MFMA_BF16_PEAK_TFLOPS,
+                unit="TFLOP/s", frac=round(flops / (ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4), traffic=None,
+                kernel="b16::gemm_kernel (bf16 MFMA GEMM, all layouts)", launches_per_step=n // steps,
+                avg_launch_us=round(ms * 1e3 / n, 2), avg_algorithmic_gflop_per_launch=round(flops / n / 1e9, 3))
+
+
+def cpu_baseline(cfg, seconds_budget=25.0):
+    """The numpy oracle (port of the reference algorithm) on host cores: full training steps
+    (forward, loss, backward, Adam) of the SAME architecture on a small batch of the same length
+    distribution, repeated until ~seconds_budget."""
+    from oracle import transformer_np as O
+    import contextlib
+    try:
+        from threadpoolctl import threadpool_limits
+    except Exception:  # pragma: no cover
+        threadpool_limits = None
+    cores = min(16, os.cpu_count() or 1)
+    rng = np.random.default_rng(0)
+    V, d, F, NL, H, dk = cfg["vocab"], cfg["d_model"], cfg["d_inner"], cfg["n_layers"], cfg["n_head"], cfg["d_k"]
+    def mat(*shape):
+        return (rng.standard_normal(shape) * np.sqrt(2.0 / (shape[0] + shape[1]))).astype(np.float32)
+    w = {"encoder.src_word_emb.weight": mat(V, d), "decoder.tgt_word_emb.weight": mat(V, d), "generator.weight": mat(V, d),
+         "encoder.position_enc.weight": O.sinusoid_table(cfg["hi"] + 4, d, 0),
+         "decoder.position_enc.weight": O.sinusoid_table(cfg["hi"] + 4, d, 0)}
+    for side, kinds in (("encoder", ("slf_attn",)), ("decoder", ("slf_attn", "enc_attn"))):
+        for i in range(NL):
+            pre = f"{side}.layer_stack.{i}."
+            for a in kinds:
+                for nm in ("w_qs", "w_ks", "w_vs"):
+                    w[pre + a + f".{nm}.weight"] = mat(H * dk, d); w[pre + a + f".{nm}.bias"] = np.zeros(H * dk, np.float32)
+                w[pre + a + ".fc.weight"] = mat(d, H * dk); w[pre + a + ".fc.bias"] = np.zeros(d, np.float32)
+                w[pre + a + ".layer_norm.weight"] = np.ones(d, np.float32); w[pre + a + ".layer_norm.bias"] = np.zeros(d, np.float32)
+            w[pre + "pos_ffn.w_1.weight"] = mat(F, d)[:, :, None]; w[pre + "pos_ffn.w_1.bias"] = np.zeros(F, np.float32)
+            w[pre + "pos_ffn.w_2.weight"] = mat(d, F)[:, :, None]; w[pre + "pos_ffn.w_2.bias"] = np.zeros(d, np.float32)
+            w[pre + "pos_ffn.layer_norm.weight"] = np.ones(d, np.float32); w[pre + "pos_ffn.layer_norm.bias"] = np.zeros(d, np.float32)
+    ocfg = O.Config(NL, H, dk, dk, d, F)
+    g = torch.Generator().manual_seed(7)
+    n_sent = 8
+    src_seq, src_pos = (x.numpy() for x in make_batch(g, n_sent, cfg["lo"], cfg["hi"], V))
+    tgt_seq, tgt_pos = (x.numpy() for x in make_batch(g, n_sent, cfg["lo"], cfg["hi"], V))
+    trainable = [k for k in w if "position_enc" not in k]
+    mom = {k: np.zeros_like(w[k]) for k in trainable}
+    var = {k: np.zeros_like(w[k]) for k in trainable}
+
+    def step(i):
+        logits, cache = O.transformer_fwd(w, ocfg, src_seq, src_pos, tgt_seq, tgt_pos)
+        _, dpred, _ = O.ls_xent(logits.reshape(-1, V), tgt_seq[:, 1:].reshape(-1), True)
+        grads = O.transformer_bwd(w, ocfg, dpred.reshape(logits.shape), cache)
+        lr = np.float32(O.noam_lr(i, d, 4000))
+        for k in trainable:
+            O.adam_step(w[k], grads[k].astype(np.float32), mom[k], var[k], i, lr)
+
+    with (threadpool_limits(limits=cores) if threadpool_limits else contextlib.nullcontext()):
+        step(1)  # warm-up
+        t0, n = time.time(), 0
+        while time.time() - t0 < seconds_budget and n < 20:
+            step(n + 2)
+            n += 1
+        dt = time.time() - t0
+    tok = int((tgt_seq[:, 1:] != PAD).sum())
+    return dict(value=round(tok * n / dt, 1), unit="target tokens/sec", cores=cores, kind="port",
+                sample=f"{n} full training steps (fwd+loss+bwd+Adam, fp32 numpy) of the same architecture on "
+                       f"{n_sent} sentences/step ({tok} target tokens), lengths U[{cfg['lo']},{cfg['hi']}], {dt:.1f} s")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    cfg = CONFIGS[args.config]
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    m, opt = build(cfg, dtype, device)
+    from specialk_amd import ops
+    from specialk_amd.parallel import GradBucketReducer
+    ops.manual_seed(1000 + rank)
+    reducer = GradBucketReducer(list(m.parameters())) if world > 1 else None
+
+    g = torch.Generator().manual_seed(7 + 1000 * rank)
+    batches = []
+    for _ in range(4):
+        s, sp = make_batch(g, cfg["batch"], cfg["lo"], cfg["hi"], cfg["vocab"])
+        t, tp = make_batch(g, cfg["batch"], cfg["lo"], cfg["hi"], cfg["vocab"])
+        batches.append(tuple(x.to(device) for x in (s, sp, t, tp)))
+    tok_per_batch = [int((b[2][:, 1:] != PAD).sum()) for b in batches]
+
+    for i in range(args.warmup):
+        train_step(m, opt, batches[i % len(batches)], reducer)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    tokens = 0
+    for i in range(args.steps):
+        train_step(m, opt, batches[i % len(batches)], reducer)
+        tokens += tok_per_batch[i % len(batches)]
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+        ttok = torch.tensor([tokens], dtype=torch.float64, device=device)
+        dist.all_reduce(ttok, op=dist.ReduceOp.SUM)
+        tokens = float(ttok.item())
+
+    out = None
+    if rank == 0:
+        out = {
+            "metric": "train target tokens/sec", "value": round(tokens / elapsed, 1), "unit": "tokens/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": cfg["desc"], "config_name": args.config, "per_gpu_sentences": cfg["batch"],
+                       "target_tokens_per_step": int(tokens / args.steps), "label_smoothing": True, "dropout": 0.1,
+                       "optimizer": "Adam(0.9,0.98,1e-9)+Noam(4000)", "parallelism": f"dp{world}"},
+        }
+    if world > 1:
+        dist.barrier()
+    if rank == 0 and world == 1:
+        if not args.no_roofline and args.dtype == "bf16":
+            out["roofline"] = gemm_roofline(m, opt, batches[0], 3)
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,103 @@
+"""Data-parallel gradient exchange: one process per GPU, bucketed RCCL all-reduce (SUM)
+overlapped with backward.
+
+Replaces the reference's single-process nn.DataParallel wrapping of encoder and decoder
+(train.py:385-388).  The loss is a token SUM (lib/TransformerModel.py:370,373), so summing the
+per-rank gradients reproduces the gradient of the concatenated global batch; no averaging.
+
+Layout: parameters are packed, in reverse registration order (the order backward produces
+gradients), into flat fp32 buckets of ~`bucket_mb`; each parameter's .grad is a view into its
+bucket, so a bucket is reduced in place with a single collective as soon as its last gradient
+has been accumulated, on RCCL's own stream while backward continues.  Bucket size: xGMI is
+point-to-point (7 links x ~153 GB/s per GPU) and RCCL's ring moves 2(N-1)/N of the bucket over
+one link pair per step, so buckets must be large enough (tens of MB) to reach link bandwidth
+yet small enough that the last bucket's exposed tail stays short.
+"""
+import torch
+import torch.distributed as dist
+
+
+class GradBucketReducer:
+    def __init__(self, params, bucket_mb=32, process_group=None):
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.params = [p for p in params if p.requires_grad]
+        seen, uniq = set(), []
+        for p in self.params:
+            if id(p) not in seen:
+                seen.add(id(p))
+                uniq.append(p)
+        self.params = uniq
+        cap = int(bucket_mb * (1 << 20) / 4)
+        self.buckets = []      # list of (flat tensor, [params])
+        cur, cur_n = [], 0
+        for p in reversed(self.params):
+            if cur and cur_n + p.numel() > cap:
+                self._close(cur, cur_n)
+                cur, cur_n = [], 0
+            cur.append(p)
+            cur_n += p.numel()
+        if cur:
+            self._close(cur, cur_n)
+        self._pending = {}
+        self._handles = []
+        self._hooks = []
+        if self.world > 1:
+            for bi, (_, plist) in enumerate(self.buckets):
+                for p in plist:
+                    self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(bi)))
+        self.zero_grad()
+
+    def _close(self, plist, n):
+        flat = torch.zeros(n, dtype=torch.float32, device=plist[0].device)
+        off = 0
+        for p in plist:
+            p.grad = flat[off:off + p.numel()].view(p.shape)
+            off += p.numel()
+        self.buckets.append((flat, list(plist)))
+
+    def _make_hook(self, bi):
+        def hook(_p):
+            self._pending[bi] -= 1
+            if self._pending[bi] == 0:
+                flat = self.buckets[bi][0]
+                self._handles.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        return hook
+
+    def zero_grad(self):
+        """Zero the flat buckets in place (gradient views stay attached to the parameters)."""
+        for bi, (flat, plist) in enumerate(self.buckets):
+            flat.zero_()
+            self._pending[bi] = len(plist)
+            for p in plist:  # a foreign zero_grad(set_to_none=True) may have detached the view
+                if p.grad is None or p.grad.data_ptr() < flat.data_ptr() or \
+                        p.grad.data_ptr() >= flat.data_ptr() + flat.numel() * 4:
+                    self._reattach(flat, plist)
+                    break
+        self._handles = []
+
+    def _reattach(self, flat, plist):
+        off = 0
+        for p in plist:
+            p.grad = flat[off:off + p.numel()].view(p.shape)
+            off += p.numel()
+
+    def finish(self):
+        """Wait for every bucket's all-reduce; buckets whose parameters got no gradient this
+        step (unused parameters) are reduced here so that all ranks stay in lock-step."""
+        if self.world > 1:
+            for bi, (flat, _) in enumerate(self.buckets):
+                if self._pending[bi] > 0:
+                    self._handles.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                    self._pending[bi] = 0
+            for h in self._handles:
+                h.wait()
+        self._handles = []
+
+
+def all_reduce_scalars(values, device):
+    """Sum a few python/torch scalars over ranks in one collective (loss, n_word, n_correct)."""
+    t = torch.as_tensor(values, dtype=torch.float64, device=device)
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t
