@@ -66,9 +66,12 @@ int skhip_gemm(int layout, const void* A, const void* B, void* C, const void* bi
                float alpha, int epilogue, int in_dtype, int out_dtype,
                void* workspace, int64_t workspace_bytes, void* stream);
 
-/* Column sums: out[n] (+)= sum_m X[m][n]  (bias gradients).  out is fp32.                */
+/* Column sums: out[n] (+)= sum_m X[m][n]  (bias gradients, the autograd backward of the
+ * `+ bias` in nn.Linear, SubLayers.py:46-48,62).  out is fp32.  workspace: optional fp32
+ * scratch (>= 64*N floats lets the rows be summed in parallel chunks, combined in a fixed
+ * order); required when accumulate != 0.                                                  */
 int skhip_colsum(const void* X, float* out, int64_t M, int64_t N, int64_t ldx, int accumulate,
-                 int dtype, void* stream);
+                 int dtype, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ---- attention ----------------------------------------------------------------------
  * Replaces ScaledDotProductAttention.forward (lib/transformer/Modules.py:17-28) together

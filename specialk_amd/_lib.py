@@ -48,7 +48,7 @@ def load():
     lib.skhip_beam_topk_ws_bytes.argtypes = [c_int, c_int, c_i64]
     lib.skhip_gemm.argtypes = [c_int, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_f32,
                                c_int, c_int, c_int, c_p, c_i64, c_p]
-    lib.skhip_colsum.argtypes = [c_p, c_p, c_i64, c_i64, c_i64, c_int, c_int, c_p]
+    lib.skhip_colsum.argtypes = [c_p, c_p, c_i64, c_i64, c_i64, c_int, c_int, c_p, c_i64, c_p]
     lib.skhip_attn_fwd.argtypes = [c_p] * 8 + [c_int] * 6 + [c_i64] * 4 + [c_f32, c_int, c_f32, c_u64, c_int, c_p]
     lib.skhip_attn_bwd.argtypes = [c_p] * 12 + [c_int] * 6 + [c_i64] * 7 + [c_f32, c_int, c_f32, c_u64, c_int, c_p]
     lib.skhip_add_ln_fwd.argtypes = [c_p] * 8 + [c_i64, c_int, c_f32, c_f32, c_u64, c_int, c_p]
@@ -135,7 +135,9 @@ def colsum(X, M, N, ldx, out=None, accumulate=False):
     lib = load()
     if out is None:
         out = torch.empty(N, dtype=torch.float32, device=X.device)
-    _check(lib.skhip_colsum(_ptr(X), _ptr(out), M, N, ldx, int(accumulate), dcode(X.dtype), _stream()), "skhip_colsum")
+    ws = workspace()
+    _check(lib.skhip_colsum(_ptr(X), _ptr(out), M, N, ldx, int(accumulate), dcode(X.dtype), _ptr(ws), ws.numel(),
+                            _stream()), "skhip_colsum")
     return out
 
 

@@ -11,14 +11,26 @@
 // tile's global loads are issued before the current tile's MFMAs so that HBM latency hides
 // under compute.
 //
-// LDS images (bf16, BK = 64):
-//   K-contiguous operand ([rows][K] in memory): [128 rows][64 k] with the eight 16-byte
-//     chunks of a row XOR-swizzled by (row & 7): the ds_read_b128 fragment reads (16 rows x
-//     one chunk per 16-lane group) are bank-conflict free.
+// The MFMA is issued with the operands swapped (B fragment first), so the accumulator tile
+// is C^T: a lane owns ONE output row and several consecutive output columns, and the
+// epilogue (bias / ReLU / ReLU-mask / accumulate) works on 16-byte vectors and stores whole
+// 16-byte pieces of a row instead of 2-byte scalars.
+//
+// LDS images (bf16, BK = 64, no padding, 16 KiB per operand tile):
+//   K-contiguous operand ([rows][K] in memory): [128 rows][64 k], the eight 16-byte chunks of
+//     a row XOR-swizzled with a per-row key chosen so that the ds_read_b128 fragment reads are
+//     bank-conflict free (A: key = row & 7; B, whose fragment rows are permuted so that a
+//     lane ends up with 16 consecutive output columns: key from bits 4-5 and 1 of the row).
 //   row-contiguous operand ([K][rows] in memory, the "T" layouts of the backward GEMMs):
-//     [64 k][128 rows] + 8 elements of padding per k-row, consumed with the transposing
-//     ds_read_b64_tr_b16 (4 k x 16 rows per 16-lane group), so no transposed copy of an
-//     activation or weight is ever materialised in HBM.
+//     [64 k][128 rows], the eight 32-byte segments of a k-row XOR-swizzled by
+//     (k & 3) | ((k >> 3) & 1) << 2, consumed with the transposing ds_read_b64_tr_b16
+//     (4 k x 16 rows per 16-lane group) — no transposed copy of an activation or weight is
+//     ever materialised in HBM.
+//
+// Loads: the FAST instantiation (16-byte aligned operands, K resp. row counts multiples of 8)
+// has no per-element guards: out-of-range rows are clamped (their results are never stored)
+// and out-of-range 8-element chunks are zero-filled by one predicate per chunk.  Anything
+// else runs the GENERIC instantiation with element-wise guards.
 #include "common.h"
 
 namespace {
@@ -35,7 +47,7 @@ struct GemmParams {
   int k_per_split;
   int tiles_m, tiles_n;
   int epi;
-  int vec_a, vec_b;  // 16-byte vector loads allowed (alignment + leading dimension)
+  int vec_c;  // C (and aux) allow 16-byte vector access
   float alpha;
 };
 
@@ -49,6 +61,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   return base + local;
 }
 
+// ---------------------------------------------------------------------------- epilogue
 template <typename TOut, typename TIn>
 __device__ __forceinline__ void epilogue_store(const GemmParams& p, float v, int row, int col) {
   v *= p.alpha;
@@ -64,61 +77,154 @@ __device__ __forceinline__ void epilogue_store(const GemmParams& p, float v, int
   C[off] = Cvt<TOut>::from_f32(v);
 }
 
-// acc[mi][ni][reg] of a 16x16 MFMA tile: row = 4*(lane>>4) + reg, col = lane & 15.
-template <typename TOut, typename TIn>
+template <typename T, int NC>
+__device__ __forceinline__ void load_cols(const T* src, float (&out)[NC]) {
+  constexpr int VN = Vec16<T>::N;
+  if constexpr (NC >= VN) {
+#pragma unroll
+    for (int i = 0; i < NC / VN; ++i) {
+      Vec16<T> v;
+      v.v = ((const decltype(v.v)*)src)[i];
+#pragma unroll
+      for (int j = 0; j < VN; ++j) out[i * VN + j] = v.get(j);
+    }
+  } else {  // 4 bf16 = 8 bytes
+    uint2 raw = *(const uint2*)src;
+    const bf16_t* e = (const bf16_t*)&raw;
+#pragma unroll
+    for (int j = 0; j < NC; ++j) out[j] = bf16_to_f32(e[j]);
+  }
+}
+
+template <typename T, int NC>
+__device__ __forceinline__ void store_cols(T* dst, const float (&v)[NC]) {
+  constexpr int VN = Vec16<T>::N;
+  if constexpr (NC >= VN) {
+#pragma unroll
+    for (int i = 0; i < NC / VN; ++i) {
+      Vec16<T> o;
+#pragma unroll
+      for (int j = 0; j < VN; ++j) o.set(j, v[i * VN + j]);
+      ((decltype(o.v)*)dst)[i] = o.v;
+    }
+  } else {
+    uint2 raw;
+    bf16_t* e = (bf16_t*)&raw;
+#pragma unroll
+    for (int j = 0; j < NC; ++j) e[j] = f32_to_bf16(v[j]);
+    *(uint2*)dst = raw;
+  }
+}
+
+// NC consecutive columns of one output row, held by one lane.
+template <typename TOut, typename TIn, int NC>
+__device__ __forceinline__ void write_cols(const GemmParams& p, float (&v)[NC], int row, int col) {
+  if (col >= p.N) return;
+  const bool full = col + NC <= p.N;
+  if (gridDim.z > 1) {  // split-K: raw partial sums to the slab of this split
+    float* w = p.ws + ((int64_t)blockIdx.z * p.M + row) * p.N + col;
+    if (full && (p.N & 3) == 0) store_cols<float, NC>(w, v);
+    else
+      for (int j = 0; j < NC; ++j) if (col + j < p.N) w[j] = v[j];
+    return;
+  }
+  if (!(full && p.vec_c)) {
+    for (int j = 0; j < NC; ++j) if (col + j < p.N) epilogue_store<TOut, TIn>(p, v[j], row, col + j);
+    return;
+  }
+  const int64_t off = (int64_t)row * p.ldc + col;
+#pragma unroll
+  for (int j = 0; j < NC; ++j) v[j] *= p.alpha;
+  if (p.epi & SK_EPI_BIAS) {
+    float b[NC];
+    load_cols<float, NC>(p.bias + col, b);
+#pragma unroll
+    for (int j = 0; j < NC; ++j) v[j] += b[j];
+  }
+  if (p.epi & SK_EPI_RELU) {
+#pragma unroll
+    for (int j = 0; j < NC; ++j) v[j] = fmaxf(v[j], 0.f);
+  }
+  if (p.epi & SK_EPI_RELU_MASK) {
+    float a[NC];
+    load_cols<TIn, NC>((const TIn*)p.aux + off, a);
+#pragma unroll
+    for (int j = 0; j < NC; ++j) v[j] = a[j] > 0.f ? v[j] : 0.f;
+  }
+  if (p.epi & SK_EPI_ACCUM) {
+    float c[NC];
+    load_cols<TOut, NC>((const TOut*)p.C + off, c);
+#pragma unroll
+    for (int j = 0; j < NC; ++j) v[j] += c[j];
+  }
+  store_cols<TOut, NC>((TOut*)p.C + off, v);
+}
+
+// acc[mi][ni] holds C^T tiles: lane l owns output row 16*mi + (l & 15); register r of tile ni
+// is output column  PERM ? 16*(l>>4) + 4*ni + r  :  16*ni + 4*(l>>4) + r   (wave-local).
+template <typename TOut, typename TIn, bool PERM>
 __device__ __forceinline__ void write_tile(const GemmParams& p, f32x4_t (&acc)[4][4], int row0, int col0, int lane) {
-  const int split = blockIdx.z;
+  const int g = lane >> 4;
 #pragma unroll
-  for (int mi = 0; mi < 4; ++mi)
+  for (int mi = 0; mi < 4; ++mi) {
+    const int row = row0 + mi * 16 + (lane & 15);
+    if (row >= p.M) continue;
+    if (PERM) {
+      float v[16];
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni) {
-      int col = col0 + ni * 16 + (lane & 15);
+      for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        int row = row0 + mi * 16 + 4 * (lane >> 4) + r;
-        if (row < p.M && col < p.N) {
-          if (gridDim.z > 1)
-            p.ws[((int64_t)split * p.M + row) * p.N + col] = acc[mi][ni][r];
-          else
-            epilogue_store<TOut, TIn>(p, acc[mi][ni][r], row, col);
-        }
+        for (int r = 0; r < 4; ++r) v[ni * 4 + r] = acc[mi][ni][r];
+      write_cols<TOut, TIn, 16>(p, v, row, col0 + 16 * g);
+    } else {
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) {
+        float v[4] = {acc[mi][ni][0], acc[mi][ni][1], acc[mi][ni][2], acc[mi][ni][3]};
+        write_cols<TOut, TIn, 4>(p, v, row, col0 + 16 * ni + 4 * g);
       }
     }
+  }
 }
 
 // ============================================================================ bf16
 namespace b16 {
 constexpr int BK = 64;
-constexpr int LDT = 136;                   // padded row (elements) of a [k][rows] image
-constexpr int OPER_BYTES = BK * LDT * 2;   // 17408 >= 128*64*2
-constexpr int SMEM_BYTES = 4 * OPER_BYTES; // 2 operands x 2 buffers
+constexpr int OPER_BYTES = 128 * BK * 2;   // 16384
+constexpr int SMEM_BYTES = 4 * OPER_BYTES; // 2 operands x 2 buffers = 64 KiB
+
+__device__ __forceinline__ int key_a(int row) { return row & 7; }
+__device__ __forceinline__ int key_b(int row) { return (((row >> 4) & 3) << 1) | ((row >> 1) & 1); }
+__device__ __forceinline__ int key_t(int k) { return (k & 3) | (((k >> 3) & 1) << 2); }
+// byte offset of element (k, col) in a [64 k][128 rows] image
+__device__ __forceinline__ int t_off(int k, int col) { return k * 256 + ((((col >> 4) ^ key_t(k)) & 7) << 5) + (col & 15) * 2; }
 
 // ---- global -> registers
-template <bool T_LAYOUT>
+template <bool T_LAYOUT, bool FAST>
 __device__ __forceinline__ void load_tile(uint4 (&reg)[4], const bf16_t* base, int64_t ld, int r0, int R, int k0,
-                                          int kend, int vec, int tid) {
+                                          int kend, int tid) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    int id = tid + 256 * i;
-    int rr, kk;  // first element of this 8-element chunk
-    if (T_LAYOUT) { kk = k0 + (id >> 4); rr = r0 + (id & 15) * 8; }
-    else          { rr = r0 + (id >> 3); kk = k0 + (id & 7) * 8; }
+    const int id = tid + 256 * i;
     uint4 v = make_uint4(0, 0, 0, 0);
     if (T_LAYOUT) {
-      if (kk < kend) {
+      const int kk = k0 + (id >> 4), rr = r0 + (id & 15) * 8;
+      if (FAST) {
+        if (kk < kend && rr + 8 <= R) v = *(const uint4*)(base + (int64_t)kk * ld + rr);
+      } else if (kk < kend) {
         const bf16_t* src = base + (int64_t)kk * ld + rr;
-        if (vec && rr + 8 <= R) v = *(const uint4*)src;
-        else {
-          bf16_t* e = (bf16_t*)&v;
+        bf16_t* e = (bf16_t*)&v;
 #pragma unroll
-          for (int j = 0; j < 8; ++j) if (rr + j < R) e[j] = src[j];
-        }
+        for (int j = 0; j < 8; ++j) if (rr + j < R) e[j] = src[j];
       }
     } else {
-      if (rr < R) {
-        const bf16_t* src = base + (int64_t)rr * ld + kk;
-        if (vec && kk + 8 <= kend) v = *(const uint4*)src;
-        else {
+      const int kk = k0 + (id & 7) * 8;
+      if (FAST) {
+        const int rr = min(r0 + (id >> 3), R - 1);  // clamped rows feed outputs that are never stored
+        if (kk + 8 <= kend) v = *(const uint4*)(base + (int64_t)rr * ld + kk);
+      } else {
+        const int rr = r0 + (id >> 3);
+        if (rr < R) {
+          const bf16_t* src = base + (int64_t)rr * ld + kk;
           bf16_t* e = (bf16_t*)&v;
 #pragma unroll
           for (int j = 0; j < 8; ++j) if (kk + j < kend) e[j] = src[j];
@@ -130,42 +236,58 @@ __device__ __forceinline__ void load_tile(uint4 (&reg)[4], const bf16_t* base, i
 }
 
 // ---- registers -> LDS
-template <bool T_LAYOUT>
+template <bool T_LAYOUT, bool IS_B>
 __device__ __forceinline__ void store_tile(const uint4 (&reg)[4], char* lds, int tid) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    int id = tid + 256 * i;
+    const int id = tid + 256 * i;
     if (T_LAYOUT) {
-      int k = id >> 4, c = id & 15;
-      *(uint4*)(lds + k * (LDT * 2) + c * 16) = reg[i];
+      const int k = id >> 4, c = id & 15;
+      *(uint4*)(lds + k * 256 + ((((c >> 1) ^ key_t(k)) & 7) << 5) + (c & 1) * 16) = reg[i];
     } else {
-      int row = id >> 3, c = id & 7;
-      *(uint4*)(lds + row * 128 + ((c ^ (row & 7)) << 4)) = reg[i];
+      const int row = id >> 3, c = id & 7;
+      const int key = IS_B ? key_b(row) : key_a(row);
+      *(uint4*)(lds + row * 128 + ((c ^ key) << 4)) = reg[i];
     }
   }
 }
 
-// ---- LDS -> MFMA fragment: lane l holds X[row l&15][k = 8*(l>>4) + j], j = 0..7
+__device__ __forceinline__ bf16x8_t tr_pair(const char* lds, int k, int col) {
+  typedef __attribute__((address_space(3))) s16x4_t* lds_v4;
+  s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(lds + t_off(k, col)));
+  s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(lds + t_off(k + 4, col)));
+  s16x8_t f = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8_t, f);
+}
+
+// A fragment (second MFMA operand): lane l holds A[row0 + (l&15)][k = 32*kk + 8*(l>>4) + j]
 template <bool T_LAYOUT>
-__device__ __forceinline__ bf16x8_t read_frag(const char* lds, int row0, int kk, int lane) {
+__device__ __forceinline__ bf16x8_t read_frag_a(const char* lds, int row0, int kk, int lane) {
   if (T_LAYOUT) {
-    int i = lane & 15, g = lane >> 4;
-    int k = kk * 32 + g * 8 + (i >> 2);
-    int col = row0 + (i & 3) * 4;
-    const char* a = lds + k * (LDT * 2) + col * 2;
-    typedef __attribute__((address_space(3))) s16x4_t* lds_v4;
-    s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(a));
-    s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(a + 4 * LDT * 2));
-    s16x8_t f = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-    return __builtin_bit_cast(bf16x8_t, f);
+    const int i = lane & 15, g = lane >> 4;
+    return tr_pair(lds, kk * 32 + g * 8 + (i >> 2), row0 + (i & 3) * 4);
   } else {
-    int row = row0 + (lane & 15);
-    int chunk = kk * 4 + (lane >> 4);
-    return *(const bf16x8_t*)(lds + row * 128 + ((chunk ^ (row & 7)) << 4));
+    const int row = row0 + (lane & 15), chunk = kk * 4 + (lane >> 4);
+    return *(const bf16x8_t*)(lds + row * 128 + ((chunk ^ key_a(row)) << 4));
   }
 }
 
-template <bool A_T, bool B_T, typename TOut>
+// B fragment (first MFMA operand) of tile ni inside the wave's 64 columns starting at col0.
+// K-contiguous B: lane rho = l&15 reads row 16*(rho>>2) + 4*ni + (rho&3)  (permuted, see write_tile).
+// T-layout B:     standard rows 16*ni + rho.
+template <bool T_LAYOUT>
+__device__ __forceinline__ bf16x8_t read_frag_b(const char* lds, int col0, int ni, int kk, int lane) {
+  if (T_LAYOUT) {
+    const int i = lane & 15, g = lane >> 4;
+    return tr_pair(lds, kk * 32 + g * 8 + (i >> 2), col0 + 16 * ni + (i & 3) * 4);
+  } else {
+    const int rho = lane & 15;
+    const int row = col0 + 16 * (rho >> 2) + 4 * ni + (rho & 3), chunk = kk * 4 + (lane >> 4);
+    return *(const bf16x8_t*)(lds + row * 128 + ((chunk ^ key_b(row)) << 4));
+  }
+}
+
+template <bool A_T, bool B_T, typename TOut, bool FAST>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -191,10 +313,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
 
   uint4 ra[4], rb[4];
   if (nk > 0) {
-    load_tile<A_T>(ra, A, p.lda, m0, p.M, kbeg, kend, p.vec_a, tid);
-    load_tile<B_T>(rb, B, p.ldb, n0, p.N, kbeg, kend, p.vec_b, tid);
-    store_tile<A_T>(ra, ldsA(0), tid);
-    store_tile<B_T>(rb, ldsB(0), tid);
+    load_tile<A_T, FAST>(ra, A, p.lda, m0, p.M, kbeg, kend, tid);
+    load_tile<B_T, FAST>(rb, B, p.ldb, n0, p.N, kbeg, kend, tid);
+    store_tile<A_T, false>(ra, ldsA(0), tid);
+    store_tile<B_T, true>(rb, ldsB(0), tid);
   }
   __syncthreads();
 
@@ -202,29 +324,29 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
     const int cur = kt & 1;
     const bool more = kt + 1 < nk;
     if (more) {
-      load_tile<A_T>(ra, A, p.lda, m0, p.M, kbeg + (kt + 1) * BK, kend, p.vec_a, tid);
-      load_tile<B_T>(rb, B, p.ldb, n0, p.N, kbeg + (kt + 1) * BK, kend, p.vec_b, tid);
+      load_tile<A_T, FAST>(ra, A, p.lda, m0, p.M, kbeg + (kt + 1) * BK, kend, tid);
+      load_tile<B_T, FAST>(rb, B, p.ldb, n0, p.N, kbeg + (kt + 1) * BK, kend, tid);
     }
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       bf16x8_t fa[4], fb[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) fa[i] = read_frag<A_T>(ldsA(cur), wrow + i * 16, kk, lane);
+      for (int i = 0; i < 4; ++i) fa[i] = read_frag_a<A_T>(ldsA(cur), wrow + i * 16, kk, lane);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) fb[i] = read_frag<B_T>(ldsB(cur), wcol + i * 16, kk, lane);
+      for (int i = 0; i < 4; ++i) fb[i] = read_frag_b<B_T>(ldsB(cur), wcol, i, kk, lane);
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni)
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[mi], fb[ni], acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[ni], fa[mi], acc[mi][ni], 0, 0, 0);
     }
     if (more) {
-      store_tile<A_T>(ra, ldsA(cur ^ 1), tid);
-      store_tile<B_T>(rb, ldsB(cur ^ 1), tid);
+      store_tile<A_T, false>(ra, ldsA(cur ^ 1), tid);
+      store_tile<B_T, true>(rb, ldsB(cur ^ 1), tid);
     }
     __syncthreads();
   }
-  write_tile<TOut, bf16_t>(p, acc, m0 + wrow, n0 + wcol, lane);
+  write_tile<TOut, bf16_t, !B_T>(p, acc, m0 + wrow, n0 + wcol, lane);
 }
 }  // namespace b16
 
@@ -236,31 +358,32 @@ constexpr int LDT = 144;   // [16 k][rows] image, padded row (floats)
 constexpr int OPER_BYTES = 128 * LDK * 4;  // 10240 >= 16*144*4
 constexpr int SMEM_BYTES = 4 * OPER_BYTES;
 
-template <bool T_LAYOUT>
+template <bool T_LAYOUT, bool FAST>
 __device__ __forceinline__ void load_tile(float4 (&reg)[2], const float* base, int64_t ld, int r0, int R, int k0,
-                                          int kend, int vec, int tid) {
+                                          int kend, int tid) {
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    int id = tid + 256 * i;
-    int rr, kk;
-    if (T_LAYOUT) { kk = k0 + (id >> 5); rr = r0 + (id & 31) * 4; }
-    else          { rr = r0 + (id >> 2); kk = k0 + (id & 3) * 4; }
+    const int id = tid + 256 * i;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (T_LAYOUT) {
-      if (kk < kend) {
+      const int kk = k0 + (id >> 5), rr = r0 + (id & 31) * 4;
+      if (FAST) {
+        if (kk < kend && rr + 4 <= R) v = *(const float4*)(base + (int64_t)kk * ld + rr);
+      } else if (kk < kend) {
         const float* src = base + (int64_t)kk * ld + rr;
-        if (vec && rr + 4 <= R) v = *(const float4*)src;
-        else {
-          float* e = (float*)&v;
+        float* e = (float*)&v;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) if (rr + j < R) e[j] = src[j];
-        }
+        for (int j = 0; j < 4; ++j) if (rr + j < R) e[j] = src[j];
       }
     } else {
-      if (rr < R) {
-        const float* src = base + (int64_t)rr * ld + kk;
-        if (vec && kk + 4 <= kend) v = *(const float4*)src;
-        else {
+      const int kk = k0 + (id & 3) * 4;
+      if (FAST) {
+        const int rr = min(r0 + (id >> 2), R - 1);
+        if (kk + 4 <= kend) v = *(const float4*)(base + (int64_t)rr * ld + kk);
+      } else {
+        const int rr = r0 + (id >> 2);
+        if (rr < R) {
+          const float* src = base + (int64_t)rr * ld + kk;
           float* e = (float*)&v;
 #pragma unroll
           for (int j = 0; j < 4; ++j) if (kk + j < kend) e[j] = src[j];
@@ -275,20 +398,20 @@ template <bool T_LAYOUT>
 __device__ __forceinline__ void store_tile(const float4 (&reg)[2], float* lds, int tid) {
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    int id = tid + 256 * i;
+    const int id = tid + 256 * i;
     if (T_LAYOUT) *(float4*)(lds + (id >> 5) * LDT + (id & 31) * 4) = reg[i];
     else          *(float4*)(lds + (id >> 2) * LDK + (id & 3) * 4) = reg[i];
   }
 }
 
-// lane l holds X[row l&15][k = l>>4] of a 4-deep k-step
+// lane l holds X[row0 + (l&15)][k = 4*kk + (l>>4)]
 template <bool T_LAYOUT>
 __device__ __forceinline__ float read_frag(const float* lds, int row0, int kk, int lane) {
-  int row = row0 + (lane & 15), k = kk * 4 + (lane >> 4);
+  const int row = row0 + (lane & 15), k = kk * 4 + (lane >> 4);
   return T_LAYOUT ? lds[k * LDT + row] : lds[row * LDK + k];
 }
 
-template <bool A_T, bool B_T>
+template <bool A_T, bool B_T, bool FAST>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -314,8 +437,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
 
   float4 ra[2], rb[2];
   if (nk > 0) {
-    load_tile<A_T>(ra, A, p.lda, m0, p.M, kbeg, kend, p.vec_a, tid);
-    load_tile<B_T>(rb, B, p.ldb, n0, p.N, kbeg, kend, p.vec_b, tid);
+    load_tile<A_T, FAST>(ra, A, p.lda, m0, p.M, kbeg, kend, tid);
+    load_tile<B_T, FAST>(rb, B, p.ldb, n0, p.N, kbeg, kend, tid);
     store_tile<A_T>(ra, ldsA(0), tid);
     store_tile<B_T>(rb, ldsB(0), tid);
   }
@@ -325,8 +448,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
     const int cur = kt & 1;
     const bool more = kt + 1 < nk;
     if (more) {
-      load_tile<A_T>(ra, A, p.lda, m0, p.M, kbeg + (kt + 1) * BK, kend, p.vec_a, tid);
-      load_tile<B_T>(rb, B, p.ldb, n0, p.N, kbeg + (kt + 1) * BK, kend, p.vec_b, tid);
+      load_tile<A_T, FAST>(ra, A, p.lda, m0, p.M, kbeg + (kt + 1) * BK, kend, tid);
+      load_tile<B_T, FAST>(rb, B, p.ldb, n0, p.N, kbeg + (kt + 1) * BK, kend, tid);
     }
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
@@ -339,7 +462,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
       for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni)
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[mi], fb[ni], acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[ni], fa[mi], acc[mi][ni], 0, 0, 0);
     }
     if (more) {
       store_tile<A_T>(ra, ldsA(cur ^ 1), tid);
@@ -347,7 +470,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
     }
     __syncthreads();
   }
-  write_tile<float, float>(p, acc, m0 + wrow, n0 + wcol, lane);
+  write_tile<float, float, false>(p, acc, m0 + wrow, n0 + wcol, lane);
 }
 }  // namespace f32
 
@@ -363,10 +486,11 @@ __global__ void splitk_reduce_kernel(GemmParams p, int splits) {
 }
 
 // ---- column sums (bias gradients): out[n] (+)= sum_m X[m][n]
+// block = 64 columns x 4 row-lanes; grid.x over column groups, grid.y over row chunks whose
+// partial sums go to partial[chunk][N]; a second kernel adds the chunks in a fixed order.
 template <typename T>
-__global__ __launch_bounds__(256) void colsum_kernel(const T* X, float* out, int64_t M, int64_t N, int64_t ldx,
-                                                     int rows_per_block, int accumulate_atomic) {
-  // block = 64 columns x 4 row-lanes; grid.x over column groups, grid.y over row chunks
+__global__ __launch_bounds__(256) void colsum_kernel(const T* X, float* partial, int64_t M, int64_t N, int64_t ldx,
+                                                     int rows_per_block) {
   __shared__ float part[4][64];
   int c = blockIdx.x * 64 + (threadIdx.x & 63);
   int rl = threadIdx.x >> 6;
@@ -377,20 +501,22 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* X, float* out, int
     for (int64_t r = r0 + rl; r < r1; r += 4) s += Cvt<T>::to_f32(X[r * ldx + c]);
   part[rl][threadIdx.x & 63] = s;
   __syncthreads();
-  if (rl == 0 && c < N) {
-    float t = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
-    if (accumulate_atomic) atomicAdd(out + c, t);
-    else out[c] = t;
-  }
+  if (rl == 0 && c < N)
+    partial[(int64_t)blockIdx.y * N + c] = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
 }
 
-template <typename T>
 __global__ void colsum_finish_kernel(const float* partial, float* out, int64_t N, int chunks, int accumulate) {
   int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (c >= N) return;
   float s = 0.f;
   for (int k = 0; k < chunks; ++k) s += partial[(int64_t)k * N + c];
   out[c] = accumulate ? out[c] + s : s;
+}
+
+template <typename K>
+int launch_gemm(K kernel, dim3 grid, size_t smem, hipStream_t stream, const GemmParams& p) {
+  hipLaunchKernelGGL(kernel, grid, dim3(256), smem, stream, p);
+  return SK_OK;
 }
 
 }  // namespace
@@ -425,8 +551,14 @@ extern "C" int skhip_gemm(int layout, const void* A, const void* B, void* C, con
   p.alpha = alpha;
   const int esz = in_dtype == SK_BF16 ? 2 : 4;
   const int vecn = 16 / esz;
-  p.vec_a = ((uintptr_t)A % 16 == 0) && (lda % vecn == 0);
-  p.vec_b = ((uintptr_t)B % 16 == 0) && (ldb % vecn == 0);
+  const int osz = out_dtype == SK_BF16 ? 2 : 4;
+  // FAST loads: aligned operands; the contiguous dimension of each operand a multiple of the
+  // 16-byte chunk (K for K-contiguous operands, the row count for row-contiguous ones).
+  bool fast = ((uintptr_t)A % 16 == 0) && (lda % vecn == 0) && ((uintptr_t)B % 16 == 0) && (ldb % vecn == 0);
+  fast = fast && ((a_t ? M : K) % vecn == 0) && ((b_t ? N : K) % vecn == 0);
+  p.vec_c = ((uintptr_t)C % 16 == 0) && (ldc % (16 / osz) == 0) &&
+            (!(epilogue & SK_EPI_RELU_MASK) || ((uintptr_t)aux % 16 == 0 && ldc % vecn == 0)) &&
+            (!(epilogue & SK_EPI_BIAS) || (uintptr_t)bias % 16 == 0);
 
   const int bk = in_dtype == SK_BF16 ? b16::BK : f32::BK;
   const int64_t tiles = (int64_t)p.tiles_m * p.tiles_n;
@@ -450,14 +582,13 @@ extern "C" int skhip_gemm(int layout, const void* A, const void* B, void* C, con
   p.k_per_split = kps;
   if (splits > 1) p.ws = (float*)workspace;
 
-  dim3 grid((unsigned)tiles, 1, (unsigned)splits), block(256);
-#define LAUNCH_B16(AT, BT, TO)                                                              \
-  do {                                                                                      \
-    static int once = sk_allow_big_lds(b16::gemm_kernel<AT, BT, TO>, b16::SMEM_BYTES);      \
-    if (once) return once;                                                                  \
-    hipLaunchKernelGGL((b16::gemm_kernel<AT, BT, TO>), grid, block, b16::SMEM_BYTES, stream, p); \
-  } while (0)
-#define LAUNCH_F32(AT, BT) hipLaunchKernelGGL((f32::gemm_kernel<AT, BT>), grid, block, f32::SMEM_BYTES, stream, p)
+  dim3 grid((unsigned)tiles, 1, (unsigned)splits);
+#define LAUNCH_B16(AT, BT, TO)                                                                              \
+  (fast ? launch_gemm(b16::gemm_kernel<AT, BT, TO, true>, grid, b16::SMEM_BYTES, stream, p)                 \
+        : launch_gemm(b16::gemm_kernel<AT, BT, TO, false>, grid, b16::SMEM_BYTES, stream, p))
+#define LAUNCH_F32(AT, BT)                                                                                  \
+  (fast ? launch_gemm(f32::gemm_kernel<AT, BT, true>, grid, f32::SMEM_BYTES, stream, p)                     \
+        : launch_gemm(f32::gemm_kernel<AT, BT, false>, grid, f32::SMEM_BYTES, stream, p))
   if (in_dtype == SK_BF16) {
     if (out_dtype == SK_BF16) {
       if (layout == SK_GEMM_NT) LAUNCH_B16(false, false, bf16_t);
@@ -488,32 +619,33 @@ extern "C" int skhip_gemm(int layout, const void* A, const void* B, void* C, con
   return SK_OK;
 }
 
+// Column sums with a fixed summation order (bitwise reproducible): the rows are cut into up
+// to 64 chunks whose partial sums go to the caller's workspace and are added in chunk order
+// by a second kernel.  Without a workspace a single chunk per column group is used.
 extern "C" int skhip_colsum(const void* X, float* out, int64_t M, int64_t N, int64_t ldx, int accumulate,
-                            int dtype, void* stream_) {
+                            int dtype, void* workspace, int64_t workspace_bytes, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   SK_CHECK_ARG(dtype == SK_F32 || dtype == SK_BF16, "skhip_colsum: bad dtype");
   SK_CHECK_ARG(M >= 0 && N > 0 && ldx >= N, "skhip_colsum: bad shape");
-  // Few row chunks, atomically combined only when more than one chunk exists.  To stay
-  // deterministic we use a single chunk per column group unless M is very large, in which
-  // case chunks are combined with float atomics after zeroing (order-dependent in the last
-  // bits); callers that need bitwise reproducibility pass M <= 65536.
+  SK_CHECK_ARG(X && out, "skhip_colsum: null pointer");
+  float* partial = (float*)workspace;
   int col_groups = (int)((N + 63) / 64);
   int chunks = 1;
   const int cus = sk_num_cus();
-  while (col_groups * chunks < 2 * cus && M / (chunks * 2) >= 256) chunks *= 2;
+  while (col_groups * chunks < 2 * cus && chunks < 64 && M / (chunks * 2) >= 128) chunks *= 2;
+  while (chunks > 1 && (!partial || (int64_t)chunks * N * 4 > workspace_bytes)) chunks /= 2;
   int rows_per_block = (int)((M + chunks - 1) / chunks);
-  if (chunks > 1 && !accumulate) {
-    if (hipMemsetAsync(out, 0, N * sizeof(float), stream) != hipSuccess) {
-      sk_set_error("skhip_colsum: memset failed");
-      return SK_ERR_LAUNCH;
-    }
-  }
-  int atomic = (chunks > 1 || accumulate) ? 1 : 0;
   dim3 grid(col_groups, chunks), block(256);
+  if (chunks == 1 && !accumulate) partial = out;  // single chunk: write the result directly
+  SK_CHECK_ARG(partial, "skhip_colsum: accumulate needs a workspace of N floats");
   if (dtype == SK_BF16)
-    hipLaunchKernelGGL((colsum_kernel<bf16_t>), grid, block, 0, stream, (const bf16_t*)X, out, M, N, ldx, rows_per_block, atomic);
+    hipLaunchKernelGGL((colsum_kernel<bf16_t>), grid, block, 0, stream, (const bf16_t*)X, partial, M, N, ldx, rows_per_block);
   else
-    hipLaunchKernelGGL((colsum_kernel<float>), grid, block, 0, stream, (const float*)X, out, M, N, ldx, rows_per_block, atomic);
+    hipLaunchKernelGGL((colsum_kernel<float>), grid, block, 0, stream, (const float*)X, partial, M, N, ldx, rows_per_block);
   SK_CHECK_LAUNCH("skhip_colsum");
+  if (partial != out) {
+    hipLaunchKernelGGL(colsum_finish_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, stream, partial, out, N, chunks, accumulate);
+    SK_CHECK_LAUNCH("skhip_colsum(finish)");
+  }
   return SK_OK;
 }
