@@ -1,0 +1,48 @@
+// Shared parameter block and mask / dropout predicates of the attention kernels
+// (attention.hip: exact fp32 vector-ALU path; attention_mfma.hip: bf16 matrix-core path).
+#pragma once
+#include "common.h"
+
+namespace skattn {
+
+struct AttnParams {
+  const void *Q, *K, *V, *O, *dO;
+  void *Oout, *dQ, *dK, *dV, *P_out;
+  float* LSE;
+  float* delta;
+  const uint8_t* key_pad;
+  const uint8_t* dense;
+  int B, H, Lq, Lk, dk, dv;
+  int64_t ldq, ldk, ldv, ldo, lddq, lddk, lddv;
+  float scale;
+  int causal;
+  uint32_t drop_thr;
+  float keep_scale;
+  uint64_t seed;
+};
+
+template <typename T>
+__device__ __forceinline__ float ld(const void* base, int64_t off) { return Cvt<T>::to_f32(((const T*)base)[off]); }
+template <typename T>
+__device__ __forceinline__ void st(void* base, int64_t off, float v) { ((T*)base)[off] = Cvt<T>::from_f32(v); }
+
+__device__ __forceinline__ bool masked(const AttnParams& p, int b, int i, int j) {
+  if (j >= p.Lk || i >= p.Lq) return true;
+  if (p.key_pad && p.key_pad[(int64_t)b * p.Lk + j]) return true;
+  if (p.causal && j > i) return true;
+  if (p.dense && p.dense[((int64_t)b * p.Lq + i) * p.Lk + j]) return true;
+  return false;
+}
+__device__ __forceinline__ bool keep(const AttnParams& p, int b, int h, int i, int j) {
+  if (!p.drop_thr) return true;
+  uint64_t idx = (((uint64_t)b * p.H + h) * p.Lq + i) * p.Lk + j;
+  return sk_keep(p.seed, idx, p.drop_thr);
+}
+
+
+}  // namespace skattn
+
+// bf16 MFMA path (attention_mfma.hip); return SK_OK after enqueueing, or a negative error.
+bool sk_attn_mfma_supported(const skattn::AttnParams& p, int dtype, bool want_p);
+int sk_attn_fwd_mfma(const skattn::AttnParams& p, hipStream_t stream);
+int sk_attn_bwd_mfma(const skattn::AttnParams& p, hipStream_t stream);

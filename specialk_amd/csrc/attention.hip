@@ -17,47 +17,16 @@
 //
 // This is the exact-fp32 path used for the <=1e-5 parity runs and the fallback for head
 // sizes the MFMA kernel does not cover.
-#include "common.h"
+#include "attention.h"
+#include <stdlib.h>
+
+using namespace skattn;
 
 namespace {
 
 constexpr int OWN = 16;    // own rows per block
 constexpr int TILE = 64;   // other rows per tile (= wave width)
 constexpr int MAXD = 128;  // max head dim
-
-struct AttnParams {
-  const void *Q, *K, *V, *O, *dO;
-  void *Oout, *dQ, *dK, *dV, *P_out;
-  float* LSE;
-  float* delta;
-  const uint8_t* key_pad;
-  const uint8_t* dense;
-  int B, H, Lq, Lk, dk, dv;
-  int64_t ldq, ldk, ldv, ldo, lddq, lddk, lddv;
-  float scale;
-  int causal;
-  uint32_t drop_thr;
-  float keep_scale;
-  uint64_t seed;
-};
-
-template <typename T>
-__device__ __forceinline__ float ld(const void* base, int64_t off) { return Cvt<T>::to_f32(((const T*)base)[off]); }
-template <typename T>
-__device__ __forceinline__ void st(void* base, int64_t off, float v) { ((T*)base)[off] = Cvt<T>::from_f32(v); }
-
-__device__ __forceinline__ bool masked(const AttnParams& p, int b, int i, int j) {
-  if (j >= p.Lk || i >= p.Lq) return true;
-  if (p.key_pad && p.key_pad[(int64_t)b * p.Lk + j]) return true;
-  if (p.causal && j > i) return true;
-  if (p.dense && p.dense[((int64_t)b * p.Lq + i) * p.Lk + j]) return true;
-  return false;
-}
-__device__ __forceinline__ bool keep(const AttnParams& p, int b, int h, int i, int j) {
-  if (!p.drop_thr) return true;
-  uint64_t idx = (((uint64_t)b * p.H + h) * p.Lq + i) * p.Lk + j;
-  return sk_keep(p.seed, idx, p.drop_thr);
-}
 
 // Stage `rows` x `dim` elements starting at row r0 of a (row stride ld, column offset col0)
 // matrix into LDS as fp32 with row stride dim+1 (conflict-free "one row per lane" reads).
@@ -295,6 +264,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
   }
 }
 
+// SKHIP_ATTN_VALU=1 forces the vector-ALU kernels for bf16 too (A/B testing of the MFMA path).
+bool force_valu() {
+  const char* e = getenv("SKHIP_ATTN_VALU");
+  return e && e[0] == '1';
+}
+
 int check_common(const char* who, int B, int H, int Lq, int Lk, int dk, int dv, float p_drop, int dtype) {
   SK_CHECK_ARG(dtype == SK_F32 || dtype == SK_BF16, "%s: bad dtype %d", who, dtype);
   SK_CHECK_ARG(B >= 0 && H > 0 && Lq >= 0 && Lk >= 0, "%s: bad shape", who);
@@ -322,6 +297,7 @@ extern "C" int skhip_attn_fwd(const void* Q, const void* K, const void* V, void*
   p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo;
   p.scale = scale; p.causal = causal;
   p.drop_thr = sk_drop_threshold(p_drop); p.keep_scale = 1.0f / (1.0f - p_drop); p.seed = seed;
+  if (Lk > 0 && !force_valu() && sk_attn_mfma_supported(p, dtype, P_out != nullptr)) return sk_attn_fwd_mfma(p, stream);
   dim3 grid((Lq + OWN - 1) / OWN, n_head, B);
   size_t smem = sizeof(float) * ((size_t)TILE * (dk + 1) + (size_t)TILE * (dv + 1) + (size_t)OWN * (dk + 1));
   if (dtype == SK_BF16) {
@@ -353,6 +329,7 @@ extern "C" int skhip_attn_bwd(const void* Q, const void* K, const void* V, const
   p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo; p.lddq = lddq; p.lddk = lddk; p.lddv = lddv;
   p.scale = scale; p.causal = causal;
   p.drop_thr = sk_drop_threshold(p_drop); p.keep_scale = 1.0f / (1.0f - p_drop); p.seed = seed;
+  if (!force_valu() && sk_attn_mfma_supported(p, dtype, false)) return sk_attn_bwd_mfma(p, stream);
   int64_t rows = (int64_t)B * n_head * Lq;
   unsigned dblocks = (unsigned)((rows + 3) / 4 < 4096 ? (rows + 3) / 4 : 4096);
   size_t smem_q = sizeof(float) * ((size_t)TILE * (dk + 1) + (size_t)TILE * (dv + 1) + (size_t)OWN * (dk + 1) + (size_t)OWN * (dv + 1));

@@ -1,0 +1,385 @@
+// bf16 attention on the matrix cores (v_mfma_f32_16x16x32_bf16), forward and backward, for
+// head sizes dk == dv in {32, 64, 128}.
+//
+// Replaces ScaledDotProductAttention.forward (lib/transformer/Modules.py:17-28) and its
+// autograd backward, plus the head split / merge copies of MultiHeadAttention
+// (lib/transformer/SubLayers.py:50-60): heads are addressed in place inside the (T, h*d)
+// projection buffers.
+//
+// One scheme serves all three kernels.  A wave OWNS 16 rows (query rows for forward and dQ,
+// key rows for dK/dV) whose operand fragments it keeps in registers, and sweeps the OTHER
+// sequence in 64-row tiles staged in LDS.  Every product is issued as
+//     D[rho][c] = sum_k X[rho][k] * Y[c][k],   X from LDS, Y from registers,
+// so the accumulator has the wave's own row on the LANE (c = lane & 15) and the other row in
+// the registers (rho = 16*tile + 4*(lane>>4) + r).  Consequences:
+//   * a softmax row is 16 values per lane plus two cross-lane steps (xor 16, 32);
+//   * the accumulator of the first product (scores / probabilities / dS), converted to bf16,
+//     IS the Y operand of the second product with no lane movement: the contraction order
+//     within a 32-deep MFMA step is (lane>>4, j) -> other row 32*s + 16*(j>>2) + 4*(lane>>4)
+//     + (j&3), and the X operand of that product (V^T, K^T, dO^T, Q^T) is fetched with the
+//     transposing ds_read_b64_tr_b16 in the same order.
+// Scores never touch HBM; backward recomputes probabilities from the forward's row
+// log-sum-exp.  dQ and dK/dV are separate launches (own rows = queries resp. keys), so no
+// atomics are needed and results are bitwise reproducible.
+#include "attention.h"
+
+using namespace skattn;
+
+namespace {
+
+constexpr int OT = 64;  // other-sequence rows per LDS tile
+
+template <int D> struct Tile {
+  static constexpr int LD = D + 8;  // padded row (elements): 16-byte aligned rows, spreads banks
+  bf16_t a[OT][LD];
+};
+
+__device__ __forceinline__ bf16x8_t ld_frag_global(const bf16_t* p) { return *(const bf16x8_t*)p; }
+
+// X fragment by rows: lane (rho = l&15, g = l>>4) <- tile[row0 + rho][32*s + 8*g .. +7]
+template <int D>
+__device__ __forceinline__ bf16x8_t x_rows(const Tile<D>& t, int row0, int s, int lane) {
+  return *(const bf16x8_t*)&t.a[row0 + (lane & 15)][32 * s + 8 * (lane >> 4)];
+}
+
+// X fragment by columns (transposed): lane (rho, g) <- tile[32*s2 + 16*(j>>2) + 4*g + (j&3)][col0 + rho]
+template <int D>
+__device__ __forceinline__ bf16x8_t x_cols(const Tile<D>& t, int col0, int s2, int lane) {
+  typedef __attribute__((address_space(3))) s16x4_t* lds_v4;
+  const int i = lane & 15, g = lane >> 4;
+  const int row = 32 * s2 + 4 * g + (i >> 2), col = col0 + 4 * (i & 3);
+  s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)&t.a[row][col]);
+  s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)&t.a[row + 16][col]);
+  s16x8_t f = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8_t, f);
+}
+
+// accumulators of other-row tiles 2*s2 and 2*s2+1 -> Y fragment of MFMA step s2
+__device__ __forceinline__ bf16x8_t pack_y(const f32x4_t& a, const f32x4_t& b) {
+  bf16x8_t f;
+  f[0] = (__bf16)a[0]; f[1] = (__bf16)a[1]; f[2] = (__bf16)a[2]; f[3] = (__bf16)a[3];
+  f[4] = (__bf16)b[0]; f[5] = (__bf16)b[1]; f[6] = (__bf16)b[2]; f[7] = (__bf16)b[3];
+  return f;
+}
+
+// Stage 64 rows x D columns (bf16) of a (row stride ld) matrix into an LDS tile; rows beyond
+// `nrows` are zero-filled.
+template <int D>
+__device__ __forceinline__ void stage_tile(Tile<D>& t, const bf16_t* base, int64_t ld, int r0, int nrows) {
+  constexpr int CH = D / 8;  // 16-byte chunks per row
+  for (int e = threadIdx.x; e < OT * CH; e += 256) {
+    const int r = e / CH, c = e - r * CH;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (r0 + r < nrows) v = *(const uint4*)(base + (int64_t)(r0 + r) * ld + c * 8);
+    *(uint4*)&t.a[r][c * 8] = v;
+  }
+}
+
+__device__ __forceinline__ float quad_max(float v) {
+  v = fmaxf(v, __shfl_xor(v, 16, 64));
+  return fmaxf(v, __shfl_xor(v, 32, 64));
+}
+__device__ __forceinline__ float quad_sum(float v) {
+  v += __shfl_xor(v, 16, 64);
+  return v + __shfl_xor(v, 32, 64);
+}
+
+// ------------------------------------------------------------------------------ forward
+template <int D>
+__global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(AttnParams p) {
+  __shared__ __attribute__((aligned(16))) Tile<D> Ks;
+  __shared__ __attribute__((aligned(16))) Tile<D> Vs;
+  __shared__ uint8_t kmask[OT];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int c = lane & 15, g = lane >> 4;
+  const int q = blockIdx.x * 64 + wave * 16 + c;
+  const int qrow = min(q, p.Lq - 1);
+  const bf16_t* Q = (const bf16_t*)p.Q + ((int64_t)b * p.Lq + qrow) * p.ldq + h * D;
+  const bf16_t* K = (const bf16_t*)p.K + (int64_t)b * p.Lk * p.ldk + h * D;
+  const bf16_t* V = (const bf16_t*)p.V + (int64_t)b * p.Lk * p.ldv + h * D;
+  bf16x8_t fq[D / 32];
+#pragma unroll
+  for (int s = 0; s < D / 32; ++s) fq[s] = ld_frag_global(Q + 32 * s + 8 * g);
+
+  float m = -INFINITY, l = 0.f;
+  f32x4_t o[D / 16];
+#pragma unroll
+  for (int t = 0; t < D / 16; ++t) o[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  for (int j0 = 0; j0 < p.Lk; j0 += OT) {
+    __syncthreads();
+    stage_tile<D>(Ks, K, p.ldk, j0, p.Lk);
+    stage_tile<D>(Vs, V, p.ldv, j0, p.Lk);
+    if (threadIdx.x < OT) {
+      const int j = j0 + threadIdx.x;
+      kmask[threadIdx.x] = (j >= p.Lk) || (p.key_pad && p.key_pad[(int64_t)b * p.Lk + j]);
+    }
+    __syncthreads();
+    f32x4_t sc[4];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      sc[kt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < D / 32; ++s)
+        sc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x_rows<D>(Ks, 16 * kt, s, lane), fq[s], sc[kt], 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int jl = 16 * kt + 4 * g + r;
+        const bool msk = kmask[jl] || (p.causal && j0 + jl > q);
+        sc[kt][r] = msk ? -INFINITY : sc[kt][r] * p.scale;
+        mx = fmaxf(mx, sc[kt][r]);
+      }
+    }
+    const float mn = fmaxf(m, quad_max(mx));
+    const bool dead = mn == -INFINITY;
+    const float alpha = dead ? 1.f : __expf(m - mn);
+    float rs = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float pr = dead ? 0.f : __expf(sc[kt][r] - mn);
+        rs += pr;
+        if (p.drop_thr) pr = keep(p, b, h, q, j0 + 16 * kt + 4 * g + r) ? pr * p.keep_scale : 0.f;
+        sc[kt][r] = pr;
+      }
+    l = l * alpha + quad_sum(rs);
+    m = mn;
+    const bf16x8_t y0 = pack_y(sc[0], sc[1]), y1 = pack_y(sc[2], sc[3]);
+#pragma unroll
+    for (int t = 0; t < D / 16; ++t) {
+      o[t] *= alpha;
+      o[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x_cols<D>(Vs, 16 * t, 0, lane), y0, o[t], 0, 0, 0);
+      o[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x_cols<D>(Vs, 16 * t, 1, lane), y1, o[t], 0, 0, 0);
+    }
+  }
+  if (q < p.Lq) {
+    const float inv = 1.0f / l;  // fully masked row: 0 * inf = NaN, like the reference's softmax
+    bf16_t* O = (bf16_t*)p.Oout + ((int64_t)b * p.Lq + q) * p.ldo + h * D;
+#pragma unroll
+    for (int t = 0; t < D / 16; ++t) {
+      uint2 w;
+      bf16_t* e = (bf16_t*)&w;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) e[r] = f32_to_bf16(o[t][r] * inv);
+      *(uint2*)(O + 16 * t + 4 * g) = w;
+    }
+    if (g == 0) p.LSE[((int64_t)b * p.H + h) * p.Lq + q] = m + __logf(l);
+  }
+}
+
+// ------------------------------------------------------------------------------ dQ (+ delta)
+template <int D>
+__global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(AttnParams p) {
+  __shared__ __attribute__((aligned(16))) Tile<D> Ks;
+  __shared__ __attribute__((aligned(16))) Tile<D> Vs;
+  __shared__ uint8_t kmask[OT];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int c = lane & 15, g = lane >> 4;
+  const int q = blockIdx.x * 64 + wave * 16 + c;
+  const int qrow = min(q, p.Lq - 1);
+  const int64_t qoff = ((int64_t)b * p.Lq + qrow);
+  const bf16_t* Q = (const bf16_t*)p.Q + qoff * p.ldq + h * D;
+  const bf16_t* dO = (const bf16_t*)p.dO + qoff * p.ldo + h * D;
+  const bf16_t* O = (const bf16_t*)p.O + qoff * p.ldo + h * D;
+  const bf16_t* K = (const bf16_t*)p.K + (int64_t)b * p.Lk * p.ldk + h * D;
+  const bf16_t* V = (const bf16_t*)p.V + (int64_t)b * p.Lk * p.ldv + h * D;
+  bf16x8_t fq[D / 32], fdo[D / 32];
+  float dl = 0.f;
+#pragma unroll
+  for (int s = 0; s < D / 32; ++s) {
+    fq[s] = ld_frag_global(Q + 32 * s + 8 * g);
+    fdo[s] = ld_frag_global(dO + 32 * s + 8 * g);
+    bf16x8_t fo = ld_frag_global(O + 32 * s + 8 * g);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dl += (float)fdo[s][j] * (float)fo[j];
+  }
+  dl = quad_sum(dl);  // delta = rowsum(dO * O)
+  const int64_t si = ((int64_t)b * p.H + h) * p.Lq + qrow;
+  const float lse = p.LSE[si];
+  if (q < p.Lq && g == 0) p.delta[si] = dl;
+
+  f32x4_t dq[D / 16];
+#pragma unroll
+  for (int t = 0; t < D / 16; ++t) dq[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  for (int j0 = 0; j0 < p.Lk; j0 += OT) {
+    __syncthreads();
+    stage_tile<D>(Ks, K, p.ldk, j0, p.Lk);
+    stage_tile<D>(Vs, V, p.ldv, j0, p.Lk);
+    if (threadIdx.x < OT) {
+      const int j = j0 + threadIdx.x;
+      kmask[threadIdx.x] = (j >= p.Lk) || (p.key_pad && p.key_pad[(int64_t)b * p.Lk + j]);
+    }
+    __syncthreads();
+    f32x4_t ds[4];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      f32x4_t sc = f32x4_t{0.f, 0.f, 0.f, 0.f}, dp = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < D / 32; ++s) {
+        sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x_rows<D>(Ks, 16 * kt, s, lane), fq[s], sc, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x_rows<D>(Vs, 16 * kt, s, lane), fdo[s], dp, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int jl = 16 * kt + 4 * g + r;
+        const bool msk = kmask[jl] || (p.causal && j0 + jl > q) || q >= p.Lq;
+        float pr = msk ? 0.f : __expf(sc[r] * p.scale - lse);
+        float dpv = dp[r];
+        if (p.drop_thr) dpv = keep(p, b, h, q, j0 + jl) ? dpv * p.keep_scale : 0.f;
+        ds[kt][r] = pr * (dpv - dl) * p.scale;
+      }
+    }
+    const bf16x8_t y0 = pack_y(ds[0], ds[1]), y1 = pack_y(ds[2], ds[3]);
+#pragma unroll
+    for (int t = 0; t < D / 16; ++t) {
+      dq[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x_cols<D>(Ks, 16 * t, 0, lane), y0, dq[t], 0, 0, 0);
+      dq[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x_cols<D>(Ks, 16 * t, 1, lane), y1, dq[t], 0, 0, 0);
+    }
+  }
+  if (q < p.Lq) {
+    bf16_t* out = (bf16_t*)p.dQ + ((int64_t)b * p.Lq + q) * p.lddq + h * D;
+#pragma unroll
+    for (int t = 0; t < D / 16; ++t) {
+      uint2 w;
+      bf16_t* e = (bf16_t*)&w;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) e[r] = f32_to_bf16(dq[t][r]);
+      *(uint2*)(out + 16 * t + 4 * g) = w;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------ dK, dV
+template <int D>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(AttnParams p) {
+  __shared__ __attribute__((aligned(16))) Tile<D> Qs;
+  __shared__ __attribute__((aligned(16))) Tile<D> dOs;
+  __shared__ float s_lse[OT], s_dl[OT];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int c = lane & 15, g = lane >> 4;
+  const int j = blockIdx.x * 64 + wave * 16 + c;  // own key row
+  const int jrow = min(j, p.Lk - 1);
+  const bf16_t* K = (const bf16_t*)p.K + ((int64_t)b * p.Lk + jrow) * p.ldk + h * D;
+  const bf16_t* V = (const bf16_t*)p.V + ((int64_t)b * p.Lk + jrow) * p.ldv + h * D;
+  const bf16_t* Q = (const bf16_t*)p.Q + (int64_t)b * p.Lq * p.ldq + h * D;
+  const bf16_t* dO = (const bf16_t*)p.dO + (int64_t)b * p.Lq * p.ldo + h * D;
+  bf16x8_t fk[D / 32], fv[D / 32];
+#pragma unroll
+  for (int s = 0; s < D / 32; ++s) {
+    fk[s] = ld_frag_global(K + 32 * s + 8 * g);
+    fv[s] = ld_frag_global(V + 32 * s + 8 * g);
+  }
+  const bool jmask = (j >= p.Lk) || (p.key_pad && p.key_pad[(int64_t)b * p.Lk + jrow]);
+
+  f32x4_t dk[D / 16], dv[D / 16];
+#pragma unroll
+  for (int t = 0; t < D / 16; ++t) { dk[t] = f32x4_t{0.f, 0.f, 0.f, 0.f}; dv[t] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+
+  for (int i0 = 0; i0 < p.Lq; i0 += OT) {
+    __syncthreads();
+    stage_tile<D>(Qs, Q, p.ldq, i0, p.Lq);
+    stage_tile<D>(dOs, dO, p.ldo, i0, p.Lq);
+    if (threadIdx.x < OT) {
+      const int i = min(i0 + (int)threadIdx.x, p.Lq - 1);
+      const int64_t si = ((int64_t)b * p.H + h) * p.Lq + i;
+      s_lse[threadIdx.x] = p.LSE[si];
+      s_dl[threadIdx.x] = p.delta[si];
+    }
+    __syncthreads();
+    f32x4_t pd[4], ds[4];
+#pragma unroll
+    for (int qt = 0; qt < 4; ++qt) {
+      f32x4_t sc = f32x4_t{0.f, 0.f, 0.f, 0.f}, dp = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < D / 32; ++s) {
+        sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x_rows<D>(Qs, 16 * qt, s, lane), fk[s], sc, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x_rows<D>(dOs, 16 * qt, s, lane), fv[s], dp, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int il = 16 * qt + 4 * g + r, i = i0 + il;
+        const bool msk = jmask || i >= p.Lq || (p.causal && j > i);
+        float pr = msk ? 0.f : __expf(sc[r] * p.scale - s_lse[il]);
+        float dpv = dp[r], pdv = pr;
+        if (p.drop_thr) {
+          const bool kp = keep(p, b, h, i, j);
+          dpv = kp ? dpv * p.keep_scale : 0.f;
+          pdv = kp ? pr * p.keep_scale : 0.f;
+        }
+        pd[qt][r] = pdv;
+        ds[qt][r] = pr * (dpv - s_dl[il]) * p.scale;
+      }
+    }
+    const bf16x8_t yp0 = pack_y(pd[0], pd[1]), yp1 = pack_y(pd[2], pd[3]);
+    const bf16x8_t ys0 = pack_y(ds[0], ds[1]), ys1 = pack_y(ds[2], ds[3]);
+#pragma unroll
+    for (int t = 0; t < D / 16; ++t) {
+      dv[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x_cols<D>(dOs, 16 * t, 0, lane), yp0, dv[t], 0, 0, 0);
+      dv[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x_cols<D>(dOs, 16 * t, 1, lane), yp1, dv[t], 0, 0, 0);
+      dk[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x_cols<D>(Qs, 16 * t, 0, lane), ys0, dk[t], 0, 0, 0);
+      dk[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x_cols<D>(Qs, 16 * t, 1, lane), ys1, dk[t], 0, 0, 0);
+    }
+  }
+  if (j < p.Lk) {
+    bf16_t* oK = (bf16_t*)p.dK + ((int64_t)b * p.Lk + j) * p.lddk + h * D;
+    bf16_t* oV = (bf16_t*)p.dV + ((int64_t)b * p.Lk + j) * p.lddv + h * D;
+#pragma unroll
+    for (int t = 0; t < D / 16; ++t) {
+      uint2 wk, wv;
+      bf16_t* ek = (bf16_t*)&wk;
+      bf16_t* ev = (bf16_t*)&wv;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { ek[r] = f32_to_bf16(dk[t][r]); ev[r] = f32_to_bf16(dv[t][r]); }
+      *(uint2*)(oK + 16 * t + 4 * g) = wk;
+      *(uint2*)(oV + 16 * t + 4 * g) = wv;
+    }
+  }
+}
+
+bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+}  // namespace
+
+bool sk_attn_mfma_supported(const AttnParams& p, int dtype, bool want_p) {
+  if (dtype != SK_BF16 || want_p || p.dense) return false;
+  if (p.dk != p.dv || !(p.dk == 32 || p.dk == 64 || p.dk == 128)) return false;
+  if (p.Lq <= 0 || p.Lk <= 0) return false;
+  if ((p.ldq | p.ldk | p.ldv | p.ldo) & 7) return false;
+  if (!aligned16(p.Q) || !aligned16(p.K) || !aligned16(p.V)) return false;
+  if (p.dQ && (((p.lddq | p.lddk | p.lddv) & 3) || !aligned16(p.dQ) || !aligned16(p.dK) || !aligned16(p.dV) ||
+               !aligned16(p.O) || !aligned16(p.dO)))
+    return false;
+  if (p.Oout && !aligned16(p.Oout)) return false;
+  return true;
+}
+
+int sk_attn_fwd_mfma(const AttnParams& p, hipStream_t stream) {
+  dim3 grid((p.Lq + 63) / 64, p.H, p.B);
+  if (p.dk == 32) hipLaunchKernelGGL(attn_fwd_mfma_kernel<32>, grid, dim3(256), 0, stream, p);
+  else if (p.dk == 64) hipLaunchKernelGGL(attn_fwd_mfma_kernel<64>, grid, dim3(256), 0, stream, p);
+  else hipLaunchKernelGGL(attn_fwd_mfma_kernel<128>, grid, dim3(256), 0, stream, p);
+  SK_CHECK_LAUNCH("skhip_attn_fwd(mfma)");
+  return SK_OK;
+}
+
+int sk_attn_bwd_mfma(const AttnParams& p, hipStream_t stream) {
+  dim3 gq((p.Lq + 63) / 64, p.H, p.B), gk((p.Lk + 63) / 64, p.H, p.B);
+  if (p.dk == 32) {
+    hipLaunchKernelGGL(attn_bwd_dq_mfma_kernel<32>, gq, dim3(256), 0, stream, p);
+    hipLaunchKernelGGL(attn_bwd_dkv_mfma_kernel<32>, gk, dim3(256), 0, stream, p);
+  } else if (p.dk == 64) {
+    hipLaunchKernelGGL(attn_bwd_dq_mfma_kernel<64>, gq, dim3(256), 0, stream, p);
+    hipLaunchKernelGGL(attn_bwd_dkv_mfma_kernel<64>, gk, dim3(256), 0, stream, p);
+  } else {
+    hipLaunchKernelGGL(attn_bwd_dq_mfma_kernel<128>, gq, dim3(256), 0, stream, p);
+    hipLaunchKernelGGL(attn_bwd_dkv_mfma_kernel<128>, gk, dim3(256), 0, stream, p);
+  }
+  SK_CHECK_LAUNCH("skhip_attn_bwd(mfma)");
+  return SK_OK;
+}

@@ -171,6 +171,35 @@ def test_attention(L, dtype, case):
     do = rnd(o.shape, dtype, g)
     for got, ref in zip(bwd(do), rbwd(do)):
         assert rel_err(got, ref) <= t
+    if dtype == torch.bfloat16 and not dense:
+        # without the probability output the bf16 call takes the MFMA kernels (dk == dv in {32,64,128})
+        o2, lse2, _, bwd2 = run_attn(L, q, k, v, keypad, causal, dtype)
+        assert rel_err(o2, ro) <= t
+        assert rel_err(lse2, lse) <= 1e-2
+        for got, ref in zip(bwd2(do), rbwd(do)):
+            assert rel_err(got, ref) <= t
+
+
+def test_attention_mfma_dropout_matches_valu(L):
+    """Same seed -> the MFMA and the vector-ALU kernels drop the same probabilities, forward and backward."""
+    import os
+    g = torch.Generator().manual_seed(5)
+    B, H, Lq, Lk, d = 3, 4, 70, 90, 64
+    dt = torch.bfloat16
+    q, k, v = rnd((B, Lq, H, d), dt, g), rnd((B, Lk, H, d), dt, g), rnd((B, Lk, H, d), dt, g)
+    lens = torch.tensor([Lk, 50, 77])
+    keypad = torch.arange(Lk)[None, :] >= lens[:, None]
+    do = rnd((B, Lq, H, d), dt, g)
+    res = {}
+    for mode in ("0", "1"):
+        os.environ["SKHIP_ATTN_VALU"] = mode
+        try:
+            o, lse, _, bwd = run_attn(L, q, k, v, keypad, False, dt, p_drop=0.1, seed=99)
+            res[mode] = (o, lse) + tuple(bwd(do))
+        finally:
+            os.environ.pop("SKHIP_ATTN_VALU", None)
+    for a, b in zip(res["0"], res["1"]):
+        assert rel_err(a, b) <= 2e-2
 
 
 def test_attention_golden(L):
