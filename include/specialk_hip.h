@@ -118,12 +118,14 @@ int skhip_add_ln_fwd(const void* x, const void* res, const float* gamma, const f
 
 /* dx = grad wrt x (through dropout), dres = grad wrt res (may alias dx when p_drop == 0).
  * dgamma/dbeta fp32 [d] are ACCUMULATED when accumulate != 0, else overwritten.
+ * dx_colsum (optional fp32 [d]) receives sum_rows dx, i.e. the bias gradient of the linear
+ * layer whose output x is (fc / w_2, SubLayers.py:62,81), saving a separate reduction pass.
  * partial_ws: fp32 scratch of at least skhip_add_ln_bwd_ws_floats(d) floats.              */
 int64_t skhip_add_ln_bwd_ws_floats(int d);
 int skhip_add_ln_bwd(const void* dy, const void* x, const void* res, const float* gamma,
                      const uint8_t* row_pad, const float* mean, const float* rstd,
-                     void* dx, void* dres, float* dgamma, float* dbeta, float* partial_ws,
-                     int64_t T, int d, float p_drop, uint64_t seed, int accumulate,
+                     void* dx, void* dres, float* dgamma, float* dbeta, float* dx_colsum,
+                     float* partial_ws, int64_t T, int d, float p_drop, uint64_t seed, int accumulate,
                      int dtype, void* stream);
 
 /* ---- embeddings ----------------------------------------------------------------------

@@ -52,7 +52,7 @@ def load():
     lib.skhip_attn_fwd.argtypes = [c_p] * 8 + [c_int] * 6 + [c_i64] * 4 + [c_f32, c_int, c_f32, c_u64, c_int, c_p]
     lib.skhip_attn_bwd.argtypes = [c_p] * 12 + [c_int] * 6 + [c_i64] * 7 + [c_f32, c_int, c_f32, c_u64, c_int, c_p]
     lib.skhip_add_ln_fwd.argtypes = [c_p] * 8 + [c_i64, c_int, c_f32, c_f32, c_u64, c_int, c_p]
-    lib.skhip_add_ln_bwd.argtypes = [c_p] * 12 + [c_i64, c_int, c_f32, c_u64, c_int, c_int, c_p]
+    lib.skhip_add_ln_bwd.argtypes = [c_p] * 13 + [c_i64, c_int, c_f32, c_u64, c_int, c_int, c_p]
     lib.skhip_embed_fwd.argtypes = [c_p] * 5 + [c_i64, c_int, c_i64, c_i64, c_int, c_p]
     lib.skhip_embed_bwd.argtypes = [c_p] * 3 + [c_i64, c_int, c_i64, c_i64, c_int, c_p]
     lib.skhip_xent_fwd_bwd.argtypes = [c_p] * 4 + [c_i64, c_i64, c_i64, c_f32, c_f32, c_i64, c_f32, c_int, c_p]
@@ -174,7 +174,8 @@ def add_ln_fwd(x, res, gamma, beta, row_pad, eps, p_drop, seed):
     return y, mean, rstd
 
 
-def add_ln_bwd(dy, x, res, gamma, row_pad, mean, rstd, p_drop, seed, dgamma=None, dbeta=None, accumulate=False):
+def add_ln_bwd(dy, x, res, gamma, row_pad, mean, rstd, p_drop, seed, dgamma=None, dbeta=None, accumulate=False,
+               want_dx_colsum=False):
     lib = load()
     T, d = x.shape
     dres = torch.empty_like(x)
@@ -183,11 +184,14 @@ def add_ln_bwd(dy, x, res, gamma, row_pad, mean, rstd, p_drop, seed, dgamma=None
         dgamma = torch.empty(d, dtype=torch.float32, device=x.device)
         dbeta = torch.empty(d, dtype=torch.float32, device=x.device)
         accumulate = False
+    dxs = torch.empty(d, dtype=torch.float32, device=x.device) if want_dx_colsum else None
     ws = workspace(int(lib.skhip_add_ln_bwd_ws_floats(d)) * 4)
     rc = lib.skhip_add_ln_bwd(_ptr(dy), _ptr(x), _ptr(res), _ptr(gamma), _ptr(row_pad), _ptr(mean), _ptr(rstd),
-                              _ptr(dx), _ptr(dres), _ptr(dgamma), _ptr(dbeta), _ptr(ws), T, d, float(p_drop),
-                              int(seed), int(accumulate), dcode(x.dtype), _stream())
+                              _ptr(dx), _ptr(dres), _ptr(dgamma), _ptr(dbeta), _ptr(dxs), _ptr(ws), T, d,
+                              float(p_drop), int(seed), int(accumulate), dcode(x.dtype), _stream())
     _check(rc, "skhip_add_ln_bwd")
+    if want_dx_colsum:
+        return dx, dres, dgamma, dbeta, dxs
     return dx, dres, dgamma, dbeta
 
 

@@ -505,6 +505,40 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* X, float* partial,
     partial[(int64_t)blockIdx.y * N + c] = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
 }
 
+// Vectorised variant: 16 row-lanes x 16 column chunks of 16 bytes per block.
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_vec_kernel(const T* X, float* partial, int64_t M, int64_t N, int64_t ldx,
+                                                         int rows_per_block) {
+  constexpr int VN = Vec16<T>::N;
+  __shared__ float part[16][16 * VN + 1];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int64_t c0 = ((int64_t)blockIdx.x * 16 + tx) * VN;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
+  float acc[VN];
+#pragma unroll
+  for (int j = 0; j < VN; ++j) acc[j] = 0.f;
+  if (c0 < N)
+    for (int64_t r = r0 + ty; r < r1; r += 16) {
+      Vec16<T> v;
+      v.v = *(const decltype(v.v)*)(X + r * ldx + c0);
+#pragma unroll
+      for (int j = 0; j < VN; ++j) acc[j] += v.get(j);
+    }
+#pragma unroll
+  for (int j = 0; j < VN; ++j) part[ty][tx * VN + j] = acc[j];
+  __syncthreads();
+  const int col = threadIdx.x;  // one thread per column of the block (16*VN <= 128 columns)
+  if (col < 16 * VN) {
+    const int64_t c = (int64_t)blockIdx.x * 16 * VN + col;
+    if (c < N) {
+      float s = 0.f;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) s += part[k][col];
+      partial[(int64_t)blockIdx.y * N + c] = s;
+    }
+  }
+}
+
 __global__ void colsum_finish_kernel(const float* partial, float* out, int64_t N, int chunks, int accumulate) {
   int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (c >= N) return;
@@ -622,6 +656,7 @@ extern "C" int skhip_gemm(int layout, const void* A, const void* B, void* C, con
 // Column sums with a fixed summation order (bitwise reproducible): the rows are cut into up
 // to 64 chunks whose partial sums go to the caller's workspace and are added in chunk order
 // by a second kernel.  Without a workspace a single chunk per column group is used.
+// (>= 128*N floats of workspace allow the full chunk count.)
 extern "C" int skhip_colsum(const void* X, float* out, int64_t M, int64_t N, int64_t ldx, int accumulate,
                             int dtype, void* workspace, int64_t workspace_bytes, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
@@ -629,16 +664,22 @@ extern "C" int skhip_colsum(const void* X, float* out, int64_t M, int64_t N, int
   SK_CHECK_ARG(M >= 0 && N > 0 && ldx >= N, "skhip_colsum: bad shape");
   SK_CHECK_ARG(X && out, "skhip_colsum: null pointer");
   float* partial = (float*)workspace;
-  int col_groups = (int)((N + 63) / 64);
+  const int vn = dtype == SK_BF16 ? 8 : 4;
+  const bool vec = ((uintptr_t)X % 16 == 0) && (ldx % vn == 0) && (N % vn == 0);
+  int col_groups = vec ? (int)((N + 16 * vn - 1) / (16 * vn)) : (int)((N + 63) / 64);
   int chunks = 1;
   const int cus = sk_num_cus();
-  while (col_groups * chunks < 2 * cus && chunks < 64 && M / (chunks * 2) >= 128) chunks *= 2;
+  while (col_groups * chunks < 4 * cus && chunks < 128 && M / (chunks * 2) >= 64) chunks *= 2;
   while (chunks > 1 && (!partial || (int64_t)chunks * N * 4 > workspace_bytes)) chunks /= 2;
   int rows_per_block = (int)((M + chunks - 1) / chunks);
   dim3 grid(col_groups, chunks), block(256);
   if (chunks == 1 && !accumulate) partial = out;  // single chunk: write the result directly
   SK_CHECK_ARG(partial, "skhip_colsum: accumulate needs a workspace of N floats");
-  if (dtype == SK_BF16)
+  if (vec && dtype == SK_BF16)
+    hipLaunchKernelGGL((colsum_vec_kernel<bf16_t>), grid, block, 0, stream, (const bf16_t*)X, partial, M, N, ldx, rows_per_block);
+  else if (vec)
+    hipLaunchKernelGGL((colsum_vec_kernel<float>), grid, block, 0, stream, (const float*)X, partial, M, N, ldx, rows_per_block);
+  else if (dtype == SK_BF16)
     hipLaunchKernelGGL((colsum_kernel<bf16_t>), grid, block, 0, stream, (const bf16_t*)X, partial, M, N, ldx, rows_per_block);
   else
     hipLaunchKernelGGL((colsum_kernel<float>), grid, block, 0, stream, (const float*)X, partial, M, N, ldx, rows_per_block);

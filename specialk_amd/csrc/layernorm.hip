@@ -11,7 +11,8 @@
 namespace {
 
 constexpr int LN_MAX_D = 2048;    // a row is held in registers: 32 values per lane
-constexpr int LN_MAX_BLOCKS = 1024;
+constexpr int LN_MAX_BLOCKS = 512;
+constexpr int LN_NPART = 3;  // dgamma, dbeta, colsum(dx)
 
 template <typename T>
 __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const T* __restrict__ x, const T* __restrict__ res,
@@ -82,8 +83,9 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const T* __restrict__ x
 }
 
 // Backward.  Each block walks rows with a grid stride and keeps per-column partial sums of
-// dgamma / dbeta in registers; they are combined across the block's 4 waves through LDS and
-// written to partial[blockIdx][2][d]; a second kernel reduces over blocks in a fixed order.
+// dgamma, dbeta and dx (the latter is the bias gradient of the linear layer that produced x)
+// in registers; they are combined across the block's 4 waves through LDS and written to
+// partial[blockIdx][3][d]; a second kernel reduces over blocks in a fixed order.
 template <typename T>
 __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                          const T* __restrict__ res, const float* __restrict__ gamma,
@@ -95,14 +97,14 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const T* __restrict__ d
   constexpr int VN = Vec16<T>::N;
   constexpr int MAXV = LN_MAX_D / (64 * VN);
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  float* red = (float*)smem_raw;  // [4 waves][2][d]
+  float* red = (float*)smem_raw;  // [4 waves][3][d]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nvec = d / VN;
-  float pg[MAXV][VN], pb[MAXV][VN];
+  float pg[MAXV][VN], pb[MAXV][VN], px[MAXV][VN];
 #pragma unroll
   for (int v = 0; v < MAXV; ++v)
 #pragma unroll
-    for (int j = 0; j < VN; ++j) { pg[v][j] = 0.f; pb[v][j] = 0.f; }
+    for (int j = 0; j < VN; ++j) { pg[v][j] = 0.f; pb[v][j] = 0.f; px[v][j] = 0.f; }
 
   for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < T_rows; row += (int64_t)gridDim.x * 4) {
     const bool pad = row_pad && row_pad[row];
@@ -146,6 +148,7 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const T* __restrict__ d
           float dxv = dz;
           if (drop_thr) dxv = sk_keep(seed, (uint64_t)(row * d + vi * VN + j), drop_thr) ? dz * keep_scale : 0.f;
           o2.set(j, dxv);
+          px[v][j] += dxv;
         }
         *(decltype(o1.v)*)(dres + row * d + vi * VN) = o1.v;
         if (dx != dres) *(decltype(o2.v)*)(dx + row * d + vi * VN) = o2.v;
@@ -159,25 +162,39 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const T* __restrict__ d
     if (vi < nvec)
 #pragma unroll
       for (int j = 0; j < VN; ++j) {
-        red[(wave * 2 + 0) * d + vi * VN + j] = pg[v][j];
-        red[(wave * 2 + 1) * d + vi * VN + j] = pb[v][j];
+        red[(wave * LN_NPART + 0) * d + vi * VN + j] = pg[v][j];
+        red[(wave * LN_NPART + 1) * d + vi * VN + j] = pb[v][j];
+        red[(wave * LN_NPART + 2) * d + vi * VN + j] = px[v][j];
       }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < 2 * d; i += 256) {
-    float s = red[i] + red[2 * d + i] + red[4 * d + i] + red[6 * d + i];
-    partial[(int64_t)blockIdx.x * 2 * d + i] = s;
+  const int nd = LN_NPART * d;
+  for (int i = threadIdx.x; i < nd; i += 256) {
+    float s = (red[i] + red[nd + i]) + (red[2 * nd + i] + red[3 * nd + i]);
+    partial[(int64_t)blockIdx.x * nd + i] = s;
   }
 }
 
-__global__ void ln_param_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dgamma,
-                                       float* __restrict__ dbeta, int d, int nblocks, int accumulate) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= 2 * d) return;
-  float s = 0.f;
-  for (int b = 0; b < nblocks; ++b) s += partial[(int64_t)b * 2 * d + i];
-  float* out = i < d ? dgamma + i : dbeta + (i - d);
-  *out = accumulate ? *out + s : s;
+// 64 columns x 4 row-lanes per block; each row-lane adds every 4th block's partial.
+__global__ __launch_bounds__(256) void ln_param_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dgamma,
+                                                              float* __restrict__ dbeta, float* __restrict__ dxsum, int d,
+                                                              int nblocks, int accumulate) {
+  __shared__ float part[4][64];
+  const int nd = LN_NPART * d;
+  const int i = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+  float s0 = 0.f, s1 = 0.f;
+  if (i < nd) {
+    int b = rl;
+    for (; b + 4 < nblocks; b += 8) { s0 += partial[(int64_t)b * nd + i]; s1 += partial[(int64_t)(b + 4) * nd + i]; }
+    if (b < nblocks) s0 += partial[(int64_t)b * nd + i];
+  }
+  part[rl][threadIdx.x & 63] = s0 + s1;
+  __syncthreads();
+  if (rl == 0 && i < nd) {
+    float s = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+    float* out = i < d ? dgamma + i : (i < 2 * d ? dbeta + (i - d) : (dxsum ? dxsum + (i - 2 * d) : nullptr));
+    if (out) *out = (accumulate && i < 2 * d) ? *out + s : s;
+  }
 }
 
 int check_d(const char* who, int d, int dtype) {
@@ -213,12 +230,12 @@ extern "C" int skhip_add_ln_fwd(const void* x, const void* res, const float* gam
   return SK_OK;
 }
 
-extern "C" int64_t skhip_add_ln_bwd_ws_floats(int d) { return (int64_t)LN_MAX_BLOCKS * 2 * d; }
+extern "C" int64_t skhip_add_ln_bwd_ws_floats(int d) { return (int64_t)LN_MAX_BLOCKS * LN_NPART * d; }
 
 extern "C" int skhip_add_ln_bwd(const void* dy, const void* x, const void* res, const float* gamma,
                                 const uint8_t* row_pad, const float* mean, const float* rstd, void* dx, void* dres,
-                                float* dgamma, float* dbeta, float* partial_ws, int64_t T, int d, float p_drop,
-                                uint64_t seed, int accumulate, int dtype, void* stream_) {
+                                float* dgamma, float* dbeta, float* dx_colsum, float* partial_ws, int64_t T, int d,
+                                float p_drop, uint64_t seed, int accumulate, int dtype, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   int rc = check_d("skhip_add_ln_bwd", d, dtype);
   if (rc) return rc;
@@ -231,7 +248,7 @@ extern "C" int skhip_add_ln_bwd(const void* dy, const void* x, const void* res, 
   if (blocks < 1) blocks = 1;
   uint32_t thr = sk_drop_threshold(p_drop);
   float ks = 1.0f / (1.0f - p_drop);
-  size_t smem = (size_t)8 * d * sizeof(float);
+  size_t smem = (size_t)4 * LN_NPART * d * sizeof(float);
   if (dtype == SK_BF16)
     hipLaunchKernelGGL((add_ln_bwd_kernel<bf16_t>), dim3((unsigned)blocks), dim3(256), smem, stream, (const bf16_t*)dy,
                        (const bf16_t*)x, (const bf16_t*)res, gamma, row_pad, mean, rstd, (bf16_t*)dx, (bf16_t*)dres,
@@ -241,8 +258,8 @@ extern "C" int skhip_add_ln_bwd(const void* dy, const void* x, const void* res, 
                        (const float*)x, (const float*)res, gamma, row_pad, mean, rstd, (float*)dx, (float*)dres,
                        partial_ws, T, d, thr, ks, seed);
   SK_CHECK_LAUNCH("skhip_add_ln_bwd");
-  hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((2 * d + 255) / 256), dim3(256), 0, stream, partial_ws, dgamma, dbeta,
-                     d, (int)blocks, accumulate);
+  hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((LN_NPART * d + 63) / 64), dim3(256), 0, stream, partial_ws, dgamma,
+                     dbeta, dx_colsum, d, (int)blocks, accumulate);
   SK_CHECK_LAUNCH("skhip_add_ln_bwd(param reduce)");
   return SK_OK;
 }

@@ -64,6 +64,14 @@ def registered_copy(p):
     return c.tensor if c is not None and c.ref() is p else None
 
 
+def _bias_grad(dy, T, N):
+    """Column sums of dy, unless the LayerNorm backward that produced dy already attached them."""
+    pre = getattr(dy, "_sk_colsum", None)
+    if pre is not None and pre[0] == dy.data_ptr():
+        return pre[1]
+    return L.colsum(dy, T, N, N)
+
+
 def _w2d(w):
     return w.reshape(w.shape[0], -1)  # Conv1d(k=1) weights (out,in,1) are linear maps (out,in)
 
@@ -128,7 +136,7 @@ class FFNFn(torch.autograd.Function):
         F = W1c.shape[0]
         dh = L.gemm(L.GEMM_NN, dy, W2c, T, F, d, d, F, aux=h, epilogue=L.EPI_RELU_MASK)
         dW2 = L.gemm(L.GEMM_TN, dy, h, d, F, T, d, F, out_dtype=torch.float32).view(W2.shape)
-        db2 = L.colsum(dy, T, d, d)
+        db2 = _bias_grad(dy, T, d)
         dx = L.gemm(L.GEMM_NN, dh, W1c, T, d, F, F, d)
         dW1 = L.gemm(L.GEMM_TN, dh, x, F, d, T, F, x.stride(0), out_dtype=torch.float32).view(W1.shape)
         db1 = L.colsum(dh, T, F, F)
@@ -196,7 +204,7 @@ class MHAFn(torch.autograd.Function):
         # output projection
         dO = L.gemm(L.GEMM_NN, dout, Woc, Tq, nv, d, d, nv)
         dWo = L.gemm(L.GEMM_TN, dout, O, d, nv, Tq, d, nv, out_dtype=f32)
-        dbo = L.colsum(dout, Tq, d, d)
+        dbo = _bias_grad(dout, Tq, d)
         # attention core
         if cfg["self_attn"]:
             dqkv = torch.empty((Tq, nq + nk + nv), dtype=dt, device=dev)
@@ -278,8 +286,11 @@ class AddLNFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x, res, gamma, mean, rstd = ctx.saved_tensors
-        dx, dres, dg, db = L.add_ln_bwd(dy.contiguous(), x, res, gamma.detach(), ctx.row_pad, mean, rstd, ctx.p_drop,
-                                        ctx.seed)
+        dx, dres, dg, db, dxs = L.add_ln_bwd(dy.contiguous(), x, res, gamma.detach(), ctx.row_pad, mean, rstd,
+                                             ctx.p_drop, ctx.seed, want_dx_colsum=True)
+        if dx.data_ptr() == dres.data_ptr():
+            dx = dx.view(dx.shape)  # distinct tensor object for the x-branch gradient
+        dx._sk_colsum = (dx.data_ptr(), dxs)  # bias gradient of the linear layer that produced x
         return dx, dres, dg, db, None, None, None
 
 

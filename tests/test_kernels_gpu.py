@@ -440,3 +440,15 @@ def test_gather_rows(L):
         L.gather_rows(src, dst, idx, 5, elems, 128, 128)
         assert torch.equal(dst[:, :elems], src[idx.long(), :elems])
         assert (dst[:, elems:] == 0).all()
+
+
+def test_add_ln_bwd_dx_colsum(L):
+    """The LayerNorm backward can emit sum_rows(dx): the bias gradient of the linear that produced x."""
+    g = torch.Generator().manual_seed(12)
+    T, d = 777, 512
+    for dtype, p in ((torch.float32, 0.0), (torch.bfloat16, 0.1)):
+        x, res, dy = (rnd((T, d), dtype, g).to(DEV) for _ in range(3))
+        gamma, beta = torch.ones(d, device=DEV), torch.zeros(d, device=DEV)
+        _, mean, rstd = L.add_ln_fwd(x, res, gamma, beta, None, 1e-5, p, 7)
+        dx, dres, dg, db, dxs = L.add_ln_bwd(dy, x, res, gamma, None, mean, rstd, p, 7, want_dx_colsum=True)
+        assert rel_err(dxs, dx.double().sum(0)) <= (1e-5 if dtype == torch.float32 else 5e-3)
