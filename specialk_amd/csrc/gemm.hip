@@ -32,6 +32,7 @@
 // and out-of-range 8-element chunks are zero-filled by one predicate per chunk.  Anything
 // else runs the GENERIC instantiation with element-wise guards.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -350,6 +351,161 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
 }
 }  // namespace b16
 
+// ============================================================================ bf16, direct-to-LDS
+// The fast path: operand tiles go global -> LDS with global_load_lds_dwordx4 (no staging
+// registers, no ds_write pass), three LDS stages of BK = 32, loads of tile kt+2 are issued
+// while tile kt is multiplied, and a COUNTED s_waitcnt vmcnt(4) + one raw s_barrier per
+// K-step lets the newer tile's loads stay in flight across the barrier.  48 KiB of LDS and
+// ~120 VGPRs per block give three resident blocks per CU.
+//
+// A direct-to-LDS load writes lane l's 16 bytes at (wave-uniform LDS base) + 16*l, so the LDS
+// image is lane-linear and every swizzle is applied to the per-lane SOURCE address:
+//   K-contiguous operand: [128 rows][32 k], 64-byte rows; chunk c of row r is stored at chunk
+//     position c ^ key(r); key = (-(r>>2)) & 3 for A and (-(r>>4)) & 3 for B (whose fragment
+//     rows are permuted, see write_tile) make every ds_read_b128 fragment read conflict-free.
+//   row-contiguous operand: [32 k][128 rows], 256-byte rows, 32-byte segments XOR key_t(k).
+// Out-of-range chunks are sourced from a zero page; out-of-range rows of a K-contiguous
+// operand are clamped (their products land in output rows/columns that are never stored).
+namespace b16g {
+constexpr int BK = 32, STAGES = 3;
+constexpr int OPER_BYTES = 128 * BK * 2;        // 8192
+constexpr int STAGE_BYTES = 2 * OPER_BYTES;     // A + B
+constexpr int SMEM_BYTES = STAGES * STAGE_BYTES; // 48 KiB
+
+__device__ uint4 g_zero_page[2];
+
+__device__ __forceinline__ int key_ka(int row) { return (-(row >> 2)) & 3; }
+__device__ __forceinline__ int key_kb(int row) { return (-(row >> 4)) & 3; }
+using b16::key_t;
+using b16::t_off;
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+
+// Source pointers of this lane's two direct-to-LDS loads per operand tile, for tile 0.
+// K-contiguous: instruction idx covers rows 16*idx..+15; T layout: k rows 4*idx..+3.
+template <bool T_LAYOUT, bool IS_B>
+struct Loader {
+  const char* ptr[2];
+  int64_t step;       // bytes per K-step
+  int kofs[2];        // first k of this lane's chunk relative to the tile start
+  bool rows_ok[2];    // T layout: the 8 rows of the chunk exist
+  __device__ __forceinline__ void init(const bf16_t* base, int64_t ld, int r0, int R, int kbeg, int wave, int lane) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int idx = wave * 2 + j;
+      if (T_LAYOUT) {
+        const int k = 4 * idx + (lane >> 4), pos = lane & 15;
+        const int col = (((pos >> 1) ^ key_t(k)) & 7) * 16 + (pos & 1) * 8;
+        kofs[j] = k;
+        rows_ok[j] = r0 + col + 8 <= R;
+        ptr[j] = (const char*)(base + (int64_t)(kbeg + k) * ld + r0 + col);
+        step = (int64_t)BK * ld * 2;
+      } else {
+        const int row = 16 * idx + (lane >> 2), cpos = lane & 3;
+        const int c = cpos ^ (IS_B ? key_kb(row) : key_ka(row));
+        kofs[j] = 8 * c;
+        rows_ok[j] = true;
+        ptr[j] = (const char*)(base + (int64_t)min(r0 + row, R - 1) * ld + kbeg + 8 * c);
+        step = BK * 2;
+      }
+    }
+  }
+  // issue the two loads of tile kt into the operand image at `lds` (wave-uniform)
+  __device__ __forceinline__ void issue(char* lds, int wave_u, int k0, int kend) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const bool ok = T_LAYOUT ? (rows_ok[j] && k0 + kofs[j] < kend) : (k0 + kofs[j] + 8 <= kend);
+      const char* src = ok ? ptr[j] : (const char*)g_zero_page;
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(lds + (wave_u * 2 + j) * 1024), 16, 0, 0);
+      ptr[j] += step;
+    }
+  }
+};
+
+template <bool T_LAYOUT>
+__device__ __forceinline__ bf16x8_t read_frag_a(const char* lds, int row0, int lane) {
+  if (T_LAYOUT) {
+    const int i = lane & 15, g = lane >> 4;
+    return b16::tr_pair(lds, g * 8 + (i >> 2), row0 + (i & 3) * 4);
+  } else {
+    const int row = row0 + (lane & 15), g = lane >> 4;
+    return *(const bf16x8_t*)(lds + row * 64 + ((g ^ key_ka(row)) << 4));
+  }
+}
+
+template <bool T_LAYOUT>
+__device__ __forceinline__ bf16x8_t read_frag_b(const char* lds, int col0, int ni, int lane) {
+  if (T_LAYOUT) {
+    const int i = lane & 15, g = lane >> 4;
+    return b16::tr_pair(lds, g * 8 + (i >> 2), col0 + 16 * ni + (i & 3) * 4);
+  } else {
+    const int rho = lane & 15, g = lane >> 4;
+    const int row = col0 + 16 * (rho >> 2) + 4 * ni + (rho & 3);
+    return *(const bf16x8_t*)(lds + row * 64 + ((g ^ key_kb(row)) << 4));
+  }
+}
+
+template <bool A_T, bool B_T, typename TOut>
+__global__ __launch_bounds__(256, 3) void gemm_kernel(GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wgid = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
+  const int tile_n = wgid % p.tiles_n, tile_m = wgid / p.tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int wrow = (wave >> 1) * 64, wcol = (wave & 1) * 64;
+
+  const int kbeg = blockIdx.z * p.k_per_split;
+  const int kend = min(p.K, kbeg + p.k_per_split);
+  const int nk = (kend - kbeg + BK - 1) / BK;
+
+  Loader<A_T, false> la;
+  Loader<B_T, true> lb;
+  la.init((const bf16_t*)p.A, p.lda, m0, p.M, kbeg, wave, lane);
+  lb.init((const bf16_t*)p.B, p.ldb, n0, p.N, kbeg, wave, lane);
+
+  f32x4_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  auto issue = [&](int stage, int kt) {
+    char* base = smem + stage * STAGE_BYTES;
+    la.issue(base, wave, kbeg + kt * BK, kend);
+    lb.issue(base + OPER_BYTES, wave, kbeg + kt * BK, kend);
+  };
+  if (nk > 0) issue(0, 0);
+  if (nk > 1) issue(1, 1);
+
+  int cs = 0, is = 2;  // stage being computed / stage being filled
+  for (int kt = 0; kt < nk; ++kt) {
+    // tile kt's four loads are older than tile kt+1's four: wait for all but the newest four
+    if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (kt + 2 < nk) issue(is, kt + 2);
+    const char* sa = smem + cs * STAGE_BYTES;
+    const char* sb = sa + OPER_BYTES;
+    bf16x8_t fa[4], fb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) fa[i] = read_frag_a<A_T>(sa, wrow + i * 16, lane);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) fb[i] = read_frag_b<B_T>(sb, wcol, i, lane);
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni)
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[ni], fa[mi], acc[mi][ni], 0, 0, 0);
+    cs = cs == STAGES - 1 ? 0 : cs + 1;
+    is = is == STAGES - 1 ? 0 : is + 1;
+  }
+  write_tile<TOut, bf16_t, !B_T>(p, acc, m0 + wrow, n0 + wcol, lane);
+}
+}  // namespace b16g
+
 // ============================================================================ fp32
 namespace f32 {
 constexpr int BK = 16;
@@ -594,7 +750,14 @@ extern "C" int skhip_gemm(int layout, const void* A, const void* B, void* C, con
             (!(epilogue & SK_EPI_RELU_MASK) || ((uintptr_t)aux % 16 == 0 && ldc % vecn == 0)) &&
             (!(epilogue & SK_EPI_BIAS) || (uintptr_t)bias % 16 == 0);
 
-  const int bk = in_dtype == SK_BF16 ? b16::BK : f32::BK;
+  // SKHIP_GEMM_STAGED=1 selects the register-staged bf16 kernel for A/B comparisons.
+  // Measured on the Transformer-base shapes (M ~ 33k, K, N in {512, 2048, 35000}): the
+  // direct-to-LDS kernel wins for NT and short-K NN, the register-staged BK=64 kernel for TN
+  // (weight gradients) and long-K NN (generator input gradient).  SKHIP_GEMM_STAGED=0/1 forces one.
+  const char* env_staged = getenv("SKHIP_GEMM_STAGED");
+  bool use_staged = layout == SK_GEMM_TN || (layout == SK_GEMM_NN && K >= 8192);
+  if (env_staged && (env_staged[0] == '0' || env_staged[0] == '1')) use_staged = env_staged[0] == '1';
+  const int bk = in_dtype == SK_BF16 ? ((fast && !use_staged) ? b16g::BK : b16::BK) : f32::BK;
   const int64_t tiles = (int64_t)p.tiles_m * p.tiles_n;
   SK_CHECK_ARG(tiles < (1ll << 31), "skhip_gemm: too many tiles");
   // deterministic split-K when the output alone cannot fill the chip
@@ -618,7 +781,8 @@ extern "C" int skhip_gemm(int layout, const void* A, const void* B, void* C, con
 
   dim3 grid((unsigned)tiles, 1, (unsigned)splits);
 #define LAUNCH_B16(AT, BT, TO)                                                                              \
-  (fast ? launch_gemm(b16::gemm_kernel<AT, BT, TO, true>, grid, b16::SMEM_BYTES, stream, p)                 \
+  (fast ? (use_staged ? launch_gemm(b16::gemm_kernel<AT, BT, TO, true>, grid, b16::SMEM_BYTES, stream, p)   \
+                      : launch_gemm(b16g::gemm_kernel<AT, BT, TO>, grid, b16g::SMEM_BYTES, stream, p))      \
         : launch_gemm(b16::gemm_kernel<AT, BT, TO, false>, grid, b16::SMEM_BYTES, stream, p))
 #define LAUNCH_F32(AT, BT)                                                                                  \
   (fast ? launch_gemm(f32::gemm_kernel<AT, BT, true>, grid, f32::SMEM_BYTES, stream, p)                     \
