@@ -1,0 +1,181 @@
+"""CPU tests of the host-side logic around the accelerated path: collation, command-line flags,
+checkpoint key handling, batch sharding and the data-parallel gradient reducer (gloo, 2 ranks)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+sys.path.insert(0, ROOT)
+from oracle import transformer_np as O  # noqa: E402
+from specialk_amd.core import constants  # noqa: E402
+from specialk_amd.core.dataset import TranslationDataset, collate_fn, paired_collate_fn  # noqa: E402
+
+
+def test_constants_match_reference_ids():
+    # core/constants.py:1-10 of the reference
+    assert (constants.PAD, constants.UNK, constants.SOS, constants.EOS) == (0, 1, 2, 3)
+    assert (constants.PAD_WORD, constants.UNK_WORD, constants.SOS_WORD, constants.EOS_WORD) == \
+        ("<blank>", "<unk>", "<s>", "</s>")
+
+
+def test_collate_matches_oracle_on_ragged_batches():
+    rng = np.random.default_rng(3)
+    for lens in ([1], [5, 2, 9], [7, 7, 7], list(rng.integers(1, 40, size=17))):
+        insts = [list(rng.integers(4, 50, size=int(n))) for n in lens]
+        seq, pos = collate_fn(insts)
+        oseq, opos = O.collate(insts)
+        assert seq.dtype == torch.int64 and pos.dtype == torch.int64
+        np.testing.assert_array_equal(seq.numpy(), oseq)
+        np.testing.assert_array_equal(pos.numpy(), opos)
+    s = paired_collate_fn([([2, 5, 3], [2, 6, 7, 3]), ([2, 3], [2, 3])])
+    assert [tuple(t.shape) for t in s] == [(2, 3), (2, 3), (2, 4), (2, 4)]
+    assert s[1].tolist() == [[1, 2, 3], [1, 2, 0]]
+
+
+def test_dataset_protocol():
+    w2i = {"<blank>": 0, "<unk>": 1, "<s>": 2, "</s>": 3, "a": 4}
+    ds = TranslationDataset(w2i, w2i, src_insts=[[2, 4, 3]], tgt_insts=[[2, 4, 4, 3]])
+    assert len(ds) == 1 and ds.src_vocab_size == 5 and ds[0] == ([2, 4, 3], [2, 4, 4, 3])
+    assert ds.tgt_idx2word[4] == "a"
+    with pytest.raises(AssertionError):
+        TranslationDataset(w2i, w2i, src_insts=[[2, 3]], tgt_insts=[[2, 3], [2, 3]])
+
+
+def test_train_flags_and_defaults():
+    from specialk_amd.train import load_args
+    o = load_args().parse_args(["-data", "d.pt", "-model", "transformer", "-epochs", "3"])
+    expect = dict(batch_size=64, layers=6, d_word_vec=300, dropout=0.1, d_model=512, d_inner_hid=2048, d_k=64,
+                  d_v=64, n_head=8, n_warmup_steps=4000, embs_share_weight=False, proj_share_weight=False,
+                  label_smoothing=False, save_mode="all", learning_rate=0.001, optim="adam", max_grad_norm=5,
+                  freeze_encoder=False, freeze_decoder=False, checkpoint_encoder="", checkpoint_decoder="",
+                  multi_gpu=False, cuda_device=None, dtype="fp32", rnn_size=500, brnn_merge="concat",
+                  start_decay_at=8, learning_rate_decay=0.5, max_generator_batches=32, input_feed=0)
+    for k, v in expect.items():
+        assert getattr(o, k) == v, k
+    with pytest.raises(SystemExit):
+        load_args().parse_args(["-model", "transformer", "-epochs", "3"])          # -data is required
+    with pytest.raises(SystemExit):
+        load_args().parse_args(["-data", "d", "-model", "gru", "-epochs", "3"])    # unknown model
+
+
+def test_translate_flags_and_defaults():
+    from specialk_amd.translate import load_args
+    o = load_args(["-model", "transformer", "-src", "s", "-vocab", "v", "-checkpoint_encoder", "e",
+                   "-checkpoint_decoder", "d"])
+    assert (o.batch_size, o.beam_size, o.n_best, o.output) == (128, 5, 1, "predictions.txt")
+    assert o.save_model is False and o.new_directory is False and o.override_max_token_seq_len is None
+
+
+def test_module_prefix_is_stripped():
+    from specialk_amd.lib.TransformerModel import _strip_module_prefix
+    sd = {"module.a.weight": 1, "module.b": 2}
+    assert list(_strip_module_prefix(sd)) == ["a.weight", "b"]
+    assert _strip_module_prefix({"a": 1}) == {"a": 1}
+
+
+def test_decode_dict_drops_eos_and_accepts_either_direction():
+    from specialk_amd.lib.nmtModel import NMTModel
+    w2i = {"<blank>": 0, "<unk>": 1, "<s>": 2, "</s>": 3, "x": 4, "y": 5}
+    hyp = [[[4, 5, 3]], [[5, 3], [4, 4]]]
+    assert NMTModel.translate_decode_dict(hyp, w2i) == ["x y", "y", "x x"]
+    assert NMTModel.translate_decode_dict(hyp, {i: w for w, i in w2i.items()}) == ["x y", "y", "x x"]
+
+
+def test_noam_schedule_matches_oracle():
+    from specialk_amd.lib.transformer.Optim import ScheduledOptim
+
+    class Opt:
+        param_groups = [{"lr": 0.0}]
+        def step(self): pass
+        def zero_grad(self): pass
+    s = ScheduledOptim(Opt(), 512, 4000)
+    for step in (1, 2, 100, 3999, 4000, 4001, 50000):
+        s.n_current_steps = step - 1
+        s._update_learning_rate()
+        assert s._optimizer.param_groups[0]["lr"] == pytest.approx(O.noam_lr(step, 512, 4000), rel=1e-12)
+
+
+# ---------------------------------------------------------------- data parallel, 2 ranks over gloo
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _dp_worker(rank, world, port, out):
+    import torch.distributed as dist
+    from specialk_amd.parallel import GradBucketReducer, all_reduce_scalars
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(6, 16), torch.nn.Tanh(), torch.nn.Linear(16, 16), torch.nn.Tanh(),
+                              torch.nn.Linear(16, 3))
+    unused = torch.nn.Parameter(torch.ones(5))
+    params = list(net.parameters()) + [unused]
+    red = GradBucketReducer(params, bucket_mb=1e-3)          # ~262 floats per bucket -> several buckets
+    assert len(red.buckets) > 1
+    x = torch.randn(8, 6, generator=torch.Generator().manual_seed(1))
+    y = torch.randn(8, 3, generator=torch.Generator().manual_seed(2))
+    per = 8 // world
+    res = []
+    for it in range(2):                                       # second pass checks zero_grad / hook re-arming
+        red.zero_grad()
+        xs, ys = x[rank * per:(rank + 1) * per], y[rank * per:(rank + 1) * per]
+        loss = ((net(xs) - ys) ** 2).sum() * (it + 1)
+        loss.backward()
+        red.finish()
+        res.append([p.grad.clone() for p in params])
+    tot = all_reduce_scalars([float(rank + 1), 2.0, 0.5], "cpu")
+    if rank == 0:
+        torch.save({"grads": res, "tot": tot}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_grad_bucket_reducer_sums_over_two_ranks(tmp_path):
+    out = str(tmp_path / "dp.pt")
+    mp.spawn(_dp_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = torch.load(out)
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(6, 16), torch.nn.Tanh(), torch.nn.Linear(16, 16), torch.nn.Tanh(),
+                              torch.nn.Linear(16, 3))
+    x = torch.randn(8, 6, generator=torch.Generator().manual_seed(1))
+    y = torch.randn(8, 3, generator=torch.Generator().manual_seed(2))
+    for it in range(2):
+        net.zero_grad()
+        (((net(x) - y) ** 2).sum() * (it + 1)).backward()
+        for g, p in zip(got["grads"][it], net.parameters()):
+            torch.testing.assert_close(g, p.grad, rtol=1e-5, atol=1e-6)
+        assert torch.count_nonzero(got["grads"][it][-1]) == 0     # the unused parameter stays zero
+    assert got["tot"].tolist() == [3.0, 4.0, 1.0]
+
+
+def test_single_process_reducer_is_a_no_op_wrapper():
+    from specialk_amd.parallel import GradBucketReducer
+    lin = torch.nn.Linear(4, 4)
+    red = GradBucketReducer(lin.parameters())
+    lin(torch.ones(2, 4)).sum().backward()
+    red.finish()
+    assert lin.weight.grad.data_ptr() == red.buckets[0][0].data_ptr() + 4 * lin.bias.numel()
+    lin.zero_grad(set_to_none=True)
+    red.zero_grad()
+    assert lin.weight.grad is not None and float(lin.weight.grad.abs().sum()) == 0.0
+
+
+def test_batch_shard_covers_batch_without_overlap(monkeypatch):
+    from specialk_amd.lib import TransformerModel as TM
+    batch = tuple(torch.arange(10)[:, None] + torch.zeros(10, 3, dtype=torch.long) for _ in range(4))
+    for world in (1, 2, 3, 4, 8, 16):
+        seen = []
+        for r in range(world):
+            monkeypatch.setattr(TM, "_world", lambda w=world: w)
+            monkeypatch.setattr(TM, "_rank", lambda r=r: r)
+            sh = TM.TransformerModel._shard(None, batch)
+            seen += sh[0][:, 0].tolist()
+        assert seen == list(range(10))
