@@ -164,7 +164,7 @@ __device__ __forceinline__ void write_cols(const GemmParams& p, float (&v)[NC], 
 // acc[mi][ni] holds C^T tiles: lane l owns output row 16*mi + (l & 15); register r of tile ni
 // is output column  PERM ? 16*(l>>4) + 4*ni + r  :  16*ni + 4*(l>>4) + r   (wave-local).
 template <typename TOut, typename TIn, bool PERM>
-__device__ __forceinline__ void write_tile(const GemmParams& p, f32x4_t (&acc)[4][4], int row0, int col0, int lane) {
+__device__ __forceinline__ void write_tile(const GemmParams& p, const f32x4_t (*acc)[4], int row0, int col0, int lane) {
   const int g = lane >> 4;
 #pragma unroll
   for (int mi = 0; mi < 4; ++mi) {
@@ -506,6 +506,132 @@ __global__ __launch_bounds__(256, 3) void gemm_kernel(GemmParams p) {
 }
 }  // namespace b16g
 
+// ============================================================================ bf16, 256x256 tile
+// Large-tile variant of the direct-to-LDS kernel for K-contiguous operands (NT).  A 128x128
+// tile needs 64 B of operand fill per clock per CU at full MFMA rate, which is all the
+// global -> LDS path delivers; a 256x256 tile halves that.  It pays when there are many more
+// tiles than CUs (the generator projection); with about one tile per CU the 128x128 kernels'
+// three resident blocks per CU hide the prologue and epilogue better.
+//
+// 512 threads = 8 waves as 2 (M) x 4 (N), each wave owns 128x64 outputs = 8x4 MFMA tiles
+// (128 fp32 accumulators per lane).  BK = 32, four LDS stages of 32 KiB (A 16 KiB + B 16 KiB),
+// one block per CU, two waves per SIMD.  The waves of the two M halves run half a K-step apart
+// (the upper half executes one extra barrier before the loop, the lower half one after it):
+// while one half multiplies tile t, the other reads its fragments of the next tile from LDS and
+// issues the loads of tile t+3, so each SIMD's MFMA pipe alternates between its two waves.
+// (A BK = 64, two-stage form of the same schedule measured 3-15 % slower.)
+//
+// Per K-step and wave:   R: barrier; 12 x ds_read_b128 (tile t); 4 x global_load_lds (tile t+3)
+//                        M: vmcnt (tile t+1 landed); lgkmcnt(0); barrier; 32 MFMAs
+// Ordering argument (barrier instances are counted per workgroup; the lower half passes
+// instance 2t entering R(t) and 2t+1 entering M(t), the upper half 2t+1 and 2t+2):
+//   read-after-load:  every wave has waited for its own loads of tile t+1 before the barrier
+//     that opens its M(t), i.e. before instance 2t+2 at the latest, and tile t+1 is first read
+//     after instance 2t+2;
+//   load-after-read:  tile t+3 overwrites the stage of tile t-1.  It is issued after instance 2t
+//     at the earliest; every wave's reads of tile t-1 were completed (lgkmcnt(0)) before the
+//     barrier that opens its M(t-1), i.e. before instance 2t at the latest.
+namespace b16x {
+constexpr int XM = 256, XN = 256, BK = 32, STAGES = 4;
+constexpr int OPER_BYTES = 256 * BK * 2;         // 16384
+constexpr int STAGE_BYTES = 2 * OPER_BYTES;      // A + B
+constexpr int SMEM_BYTES = STAGES * STAGE_BYTES;  // 128 KiB
+
+using b16g::Loader;
+using b16g::key_ka;
+using b16g::key_kb;
+
+template <typename TOut>
+__global__ __launch_bounds__(512, 1) void gemm_kernel(GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wgid = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
+  const int tile_n = wgid % p.tiles_n, tile_m = wgid / p.tiles_n;
+  const int m0 = tile_m * XM, n0 = tile_n * XN;
+  const int wrow = (wave >> 2) * 128, wcol = (wave & 3) * 64;
+
+  const int kbeg = blockIdx.z * p.k_per_split;
+  const int kend = min(p.K, kbeg + p.k_per_split);
+  const int nk = (kend - kbeg + BK - 1) / BK;
+
+  Loader<false, false> la;
+  Loader<false, true> lb;
+  la.init((const bf16_t*)p.A, p.lda, m0, p.M, kbeg, wave, lane);
+  lb.init((const bf16_t*)p.B, p.ldb, n0, p.N, kbeg, wave, lane);
+
+  f32x4_t acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  auto issue = [&](int stage, int kt) {
+    char* base = smem + stage * STAGE_BYTES;
+    la.issue(base, wave, kbeg + kt * BK, kend);
+    lb.issue(base + OPER_BYTES, wave, kbeg + kt * BK, kend);
+  };
+  if (nk > 0) issue(0, 0);
+  if (nk > 1) issue(1, 1);
+  if (nk > 2) issue(2, 2);
+  // tile 0 must have landed before the first R phase
+  if (nk > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if (nk > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (wave >= 4) __builtin_amdgcn_s_barrier();  // upper half runs half a K-step behind
+
+  // per-lane fragment offsets inside a stage
+  int offa[8], offb[4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int row = wrow + i * 16 + (lane & 15);
+    offa[i] = row * 64 + (((lane >> 4) ^ key_ka(row)) << 4);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int rho = lane & 15;
+    const int row = wcol + 16 * (rho >> 2) + 4 * i + (rho & 3);
+    offb[i] = OPER_BYTES + row * 64 + (((lane >> 4) ^ key_kb(row)) << 4);
+  }
+
+  int cs = 0, is = 3;  // stage being computed / stage being filled
+  for (int kt = 0; kt < nk; ++kt) {
+    // ---- R: fragments of tile kt, loads of tile kt+3
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    const char* st = smem + cs * STAGE_BYTES;
+    bf16x8_t fb[4], fa[8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) fb[i] = *(const bf16x8_t*)(st + offb[i]);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) fa[i] = *(const bf16x8_t*)(st + offa[i]);
+    if (kt + 3 < nk) issue(is, kt + 3);
+    // ---- M: tile kt+1 landed (this wave's part), own LDS reads done, then multiply
+    if (kt + 3 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni)
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[ni], fa[mi], acc[mi][ni], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    cs = cs == STAGES - 1 ? 0 : cs + 1;
+    is = is == STAGES - 1 ? 0 : is + 1;
+  }
+  if (wave < 4) __builtin_amdgcn_s_barrier();  // balances the upper half's extra barrier
+
+  write_tile<TOut, bf16_t, true>(p, acc, m0 + wrow, n0 + wcol, lane);
+  write_tile<TOut, bf16_t, true>(p, acc + 4, m0 + wrow + 64, n0 + wcol, lane);
+}
+}  // namespace b16x
+
 // ============================================================================ fp32
 namespace f32 {
 constexpr int BK = 16;
@@ -695,12 +821,28 @@ __global__ __launch_bounds__(256) void colsum_vec_kernel(const T* X, float* part
   }
 }
 
-__global__ void colsum_finish_kernel(const float* partial, float* out, int64_t N, int chunks, int accumulate) {
-  int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (c >= N) return;
-  float s = 0.f;
-  for (int k = 0; k < chunks; ++k) s += partial[(int64_t)k * N + c];
-  out[c] = accumulate ? out[c] + s : s;
+// Adds the chunk partials in a fixed order: block = 64 columns x 4 chunk-lanes; lane q sums
+// chunks q, q+4, ... (independent loads in flight), then the four lane sums are combined as
+// (0 + 1) + (2 + 3).
+__global__ __launch_bounds__(256) void colsum_finish_kernel(const float* partial, float* out, int64_t N, int chunks, int accumulate) {
+  __shared__ float part[4][64];
+  const int cl = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int64_t c = blockIdx.x * 64ll + cl;
+  float s0 = 0.f, s1 = 0.f;
+  if (c < N) {
+    int k = q;
+    for (; k + 4 < chunks; k += 8) {
+      s0 += partial[(int64_t)k * N + c];
+      s1 += partial[(int64_t)(k + 4) * N + c];
+    }
+    if (k < chunks) s0 += partial[(int64_t)k * N + c];
+  }
+  part[q][cl] = s0 + s1;
+  __syncthreads();
+  if (q == 0 && c < N) {
+    const float s = (part[0][cl] + part[1][cl]) + (part[2][cl] + part[3][cl]);
+    out[c] = accumulate ? out[c] + s : s;
+  }
 }
 
 template <typename K>
@@ -757,7 +899,18 @@ extern "C" int skhip_gemm(int layout, const void* A, const void* B, void* C, con
   const char* env_staged = getenv("SKHIP_GEMM_STAGED");
   bool use_staged = layout == SK_GEMM_TN || (layout == SK_GEMM_NN && K >= 8192);
   if (env_staged && (env_staged[0] == '0' || env_staged[0] == '1')) use_staged = env_staged[0] == '1';
-  const int bk = in_dtype == SK_BF16 ? ((fast && !use_staged) ? b16g::BK : b16::BK) : f32::BK;
+  // 256x256-tile kernel: K-contiguous operands (NT) with many more 256-tiles than CUs.
+  // SKHIP_GEMM_BIG=0/1 forces the choice (1 still requires NT + aligned operands).
+  const char* env_big = getenv("SKHIP_GEMM_BIG");
+  bool use_big = in_dtype == SK_BF16 && fast && layout == SK_GEMM_NT && !use_staged &&
+                 ((M + 255) / 256) * ((N + 255) / 256) >= 8 * sk_num_cus();
+  if (env_big && env_big[0] == '0') use_big = false;
+  if (env_big && env_big[0] == '1') use_big = in_dtype == SK_BF16 && fast && layout == SK_GEMM_NT;
+  if (use_big) {
+    p.tiles_m = (int)((M + b16x::XM - 1) / b16x::XM);
+    p.tiles_n = (int)((N + b16x::XN - 1) / b16x::XN);
+  }
+  const int bk = in_dtype == SK_BF16 ? (use_big ? b16x::BK : (fast && !use_staged) ? b16g::BK : b16::BK) : f32::BK;
   const int64_t tiles = (int64_t)p.tiles_m * p.tiles_n;
   SK_CHECK_ARG(tiles < (1ll << 31), "skhip_gemm: too many tiles");
   // deterministic split-K when the output alone cannot fill the chip
@@ -787,7 +940,16 @@ extern "C" int skhip_gemm(int layout, const void* A, const void* B, void* C, con
 #define LAUNCH_F32(AT, BT)                                                                                  \
   (fast ? launch_gemm(f32::gemm_kernel<AT, BT, true>, grid, f32::SMEM_BYTES, stream, p)                     \
         : launch_gemm(f32::gemm_kernel<AT, BT, false>, grid, f32::SMEM_BYTES, stream, p))
-  if (in_dtype == SK_BF16) {
+  if (use_big) {
+    int rc;
+    if (out_dtype == SK_BF16) {
+      if ((rc = sk_allow_big_lds(b16x::gemm_kernel<bf16_t>, b16x::SMEM_BYTES))) return rc;
+      hipLaunchKernelGGL(b16x::gemm_kernel<bf16_t>, grid, dim3(512), b16x::SMEM_BYTES, stream, p);
+    } else {
+      if ((rc = sk_allow_big_lds(b16x::gemm_kernel<float>, b16x::SMEM_BYTES))) return rc;
+      hipLaunchKernelGGL(b16x::gemm_kernel<float>, grid, dim3(512), b16x::SMEM_BYTES, stream, p);
+    }
+  } else if (in_dtype == SK_BF16) {
     if (out_dtype == SK_BF16) {
       if (layout == SK_GEMM_NT) LAUNCH_B16(false, false, bf16_t);
       else if (layout == SK_GEMM_NN) LAUNCH_B16(false, true, bf16_t);
@@ -849,7 +1011,7 @@ extern "C" int skhip_colsum(const void* X, float* out, int64_t M, int64_t N, int
     hipLaunchKernelGGL((colsum_kernel<float>), grid, block, 0, stream, (const float*)X, partial, M, N, ldx, rows_per_block);
   SK_CHECK_LAUNCH("skhip_colsum");
   if (partial != out) {
-    hipLaunchKernelGGL(colsum_finish_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, stream, partial, out, N, chunks, accumulate);
+    hipLaunchKernelGGL(colsum_finish_kernel, dim3((unsigned)((N + 63) / 64)), dim3(256), 0, stream, partial, out, N, chunks, accumulate);
     SK_CHECK_LAUNCH("skhip_colsum(finish)");
   }
   return SK_OK;

@@ -10,11 +10,15 @@
 
 namespace {
 
-constexpr int LN_MAX_D = 2048;    // a row is held in registers: 32 values per lane
-constexpr int LN_MAX_BLOCKS = 512;
+constexpr int LN_MAX_D = 2048;    // a row is held in registers: up to 32 values per lane
+constexpr int LN_MAX_BLOCKS = 1024;
 constexpr int LN_NPART = 3;  // dgamma, dbeta, colsum(dx)
 
-template <typename T>
+// MAXV = 16-byte vectors per lane (compile time, so that a d = 512 bf16 row costs 8 registers,
+// not 32).  Every wave walks its rows two at a time and issues the loads of both rows before it
+// reduces either: with one row in flight per wave the kernels were latency bound at a third of
+// the HBM rate.
+template <typename T, int MAXV>
 __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const T* __restrict__ x, const T* __restrict__ res,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                                          const uint8_t* __restrict__ row_pad, T* __restrict__ y,
@@ -22,61 +26,75 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const T* __restrict__ x
                                                          int64_t T_rows, int d, float eps, uint32_t drop_thr,
                                                          float keep_scale, uint64_t seed) {
   constexpr int VN = Vec16<T>::N;
-  constexpr int MAXV = LN_MAX_D / (64 * VN);
+  typedef decltype(Vec16<T>().v) raw_t;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nvec = d / VN;  // vectors per row
-  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < T_rows; row += (int64_t)gridDim.x * 4) {
-    const T* xr = x + row * d;
-    const T* rr = res + row * d;
-    float z[MAXV][VN];
-    float sum = 0.f;
+  const int64_t stride = (int64_t)gridDim.x * 4;
+  for (int64_t row0 = (int64_t)blockIdx.x * 4 + wave; row0 < T_rows; row0 += 2 * stride) {
+    Vec16<T> a[2][MAXV], b[2][MAXV];
 #pragma unroll
-    for (int v = 0; v < MAXV; ++v) {
-      int vi = lane + v * 64;
-      if (vi < nvec) {
-        Vec16<T> a, b;
-        a.v = *(const decltype(a.v)*)(xr + vi * VN);
-        b.v = *(const decltype(b.v)*)(rr + vi * VN);
+    for (int r = 0; r < 2; ++r) {
+      const int64_t row = row0 + r * stride;
+      if (row < T_rows)
 #pragma unroll
-        for (int j = 0; j < VN; ++j) {
-          float xv = a.get(j);
-          if (drop_thr) xv = sk_keep(seed, (uint64_t)(row * d + vi * VN + j), drop_thr) ? xv * keep_scale : 0.f;
-          z[v][j] = b.get(j) + xv;
-          sum += z[v][j];
-        }
-      }
-    }
-    const float mean = wave_sum(sum) / (float)d;
-    float sq = 0.f;
-#pragma unroll
-    for (int v = 0; v < MAXV; ++v)
-      if (lane + v * 64 < nvec)
-#pragma unroll
-        for (int j = 0; j < VN; ++j) { float c = z[v][j] - mean; sq += c * c; }
-    const float var = wave_sum(sq) / (float)d;
-    const float rstd = 1.0f / sqrtf(var + eps);
-    const bool pad = row_pad && row_pad[row];
-    if (lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
-    T* yr = y + row * d;
-#pragma unroll
-    for (int v = 0; v < MAXV; ++v) {
-      int vi = lane + v * 64;
-      if (vi < nvec) {
-        Vec16<T> o;
-        const float4* g4 = (const float4*)(gamma + vi * VN);
-        const float4* b4 = (const float4*)(beta + vi * VN);
-#pragma unroll
-        for (int j4 = 0; j4 < VN / 4; ++j4) {
-          float4 g = g4[j4], b = b4[j4];
-          const float gg[4] = {g.x, g.y, g.z, g.w}, bb[4] = {b.x, b.y, b.z, b.w};
-#pragma unroll
-          for (int jj = 0; jj < 4; ++jj) {
-            int j = j4 * 4 + jj;
-            float val = (z[v][j] - mean) * rstd * gg[jj] + bb[jj];
-            o.set(j, pad ? 0.f : val);
+        for (int v = 0; v < MAXV; ++v) {
+          const int vi = lane + v * 64;
+          if (vi < nvec) {
+            a[r][v].v = *(const raw_t*)(x + row * d + vi * VN);
+            b[r][v].v = *(const raw_t*)(res + row * d + vi * VN);
           }
         }
-        *(decltype(o.v)*)(yr + vi * VN) = o.v;
+    }
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int64_t row = row0 + r * stride;
+      if (row >= T_rows) break;
+      float z[MAXV][VN];
+      float sum = 0.f;
+#pragma unroll
+      for (int v = 0; v < MAXV; ++v) {
+        const int vi = lane + v * 64;
+        if (vi < nvec)
+#pragma unroll
+          for (int j = 0; j < VN; ++j) {
+            float xv = a[r][v].get(j);
+            if (drop_thr) xv = sk_keep(seed, (uint64_t)(row * d + vi * VN + j), drop_thr) ? xv * keep_scale : 0.f;
+            z[v][j] = b[r][v].get(j) + xv;
+            sum += z[v][j];
+          }
+      }
+      const float mean = wave_sum(sum) / (float)d;
+      float sq = 0.f;
+#pragma unroll
+      for (int v = 0; v < MAXV; ++v)
+        if (lane + v * 64 < nvec)
+#pragma unroll
+          for (int j = 0; j < VN; ++j) { float c = z[v][j] - mean; sq += c * c; }
+      const float var = wave_sum(sq) / (float)d;
+      const float rstd = 1.0f / sqrtf(var + eps);
+      const bool pad = row_pad && row_pad[row];
+      if (lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
+      T* yr = y + row * d;
+#pragma unroll
+      for (int v = 0; v < MAXV; ++v) {
+        const int vi = lane + v * 64;
+        if (vi < nvec) {
+          Vec16<T> o;
+          const float4* g4 = (const float4*)(gamma + vi * VN);
+          const float4* b4 = (const float4*)(beta + vi * VN);
+#pragma unroll
+          for (int j4 = 0; j4 < VN / 4; ++j4) {
+            float4 g = g4[j4], bt = b4[j4];
+            const float gg[4] = {g.x, g.y, g.z, g.w}, bb[4] = {bt.x, bt.y, bt.z, bt.w};
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+              const int j = j4 * 4 + jj;
+              const float val = (z[v][j] - mean) * rstd * gg[jj] + bb[jj];
+              o.set(j, pad ? 0.f : val);
+            }
+          }
+          *(raw_t*)(yr + vi * VN) = o.v;
+        }
       }
     }
   }
@@ -86,7 +104,7 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const T* __restrict__ x
 // dgamma, dbeta and dx (the latter is the bias gradient of the linear layer that produced x)
 // in registers; they are combined across the block's 4 waves through LDS and written to
 // partial[blockIdx][3][d]; a second kernel reduces over blocks in a fixed order.
-template <typename T>
+template <typename T, int MAXV>
 __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                          const T* __restrict__ res, const float* __restrict__ gamma,
                                                          const uint8_t* __restrict__ row_pad,
@@ -95,70 +113,96 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const T* __restrict__ d
                                                          int64_t T_rows, int d, uint32_t drop_thr, float keep_scale,
                                                          uint64_t seed) {
   constexpr int VN = Vec16<T>::N;
-  constexpr int MAXV = LN_MAX_D / (64 * VN);
+  typedef decltype(Vec16<T>().v) raw_t;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float* red = (float*)smem_raw;  // [4 waves][3][d]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nvec = d / VN;
-  float pg[MAXV][VN], pb[MAXV][VN], px[MAXV][VN];
+  float pg[MAXV][VN], pb[MAXV][VN], px[MAXV][VN], gm[MAXV][VN];
 #pragma unroll
   for (int v = 0; v < MAXV; ++v)
 #pragma unroll
-    for (int j = 0; j < VN; ++j) { pg[v][j] = 0.f; pb[v][j] = 0.f; px[v][j] = 0.f; }
+    for (int j = 0; j < VN; ++j) {
+      pg[v][j] = 0.f; pb[v][j] = 0.f; px[v][j] = 0.f;
+      const int c = (lane + v * 64) * VN + j;
+      gm[v][j] = c < d ? gamma[c] : 0.f;
+    }
 
-  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < T_rows; row += (int64_t)gridDim.x * 4) {
-    const bool pad = row_pad && row_pad[row];
-    const float mean = mean_in[row], rstd = rstd_in[row];
-    float xhat[MAXV][VN], dxh[MAXV][VN];
-    float s1 = 0.f, s2 = 0.f;
+  const int64_t stride = (int64_t)gridDim.x * 4;
+  for (int64_t row0 = (int64_t)blockIdx.x * 4 + wave; row0 < T_rows; row0 += 2 * stride) {
+    Vec16<T> a[2][MAXV], b[2][MAXV], g[2][MAXV];
+    float mean_r[2], rstd_r[2];
+    bool pad_r[2];
 #pragma unroll
-    for (int v = 0; v < MAXV; ++v) {
-      int vi = lane + v * 64;
-      if (vi < nvec) {
-        Vec16<T> a, b, g;
-        a.v = *(const decltype(a.v)*)(x + row * d + vi * VN);
-        b.v = *(const decltype(b.v)*)(res + row * d + vi * VN);
-        g.v = *(const decltype(g.v)*)(dy + row * d + vi * VN);
+    for (int r = 0; r < 2; ++r) {
+      const int64_t row = row0 + r * stride;
+      if (row < T_rows) {
+        mean_r[r] = mean_in[row];
+        rstd_r[r] = rstd_in[row];
+        pad_r[r] = row_pad && row_pad[row];
 #pragma unroll
-        for (int j = 0; j < VN; ++j) {
-          float xv = a.get(j);
-          if (drop_thr) xv = sk_keep(seed, (uint64_t)(row * d + vi * VN + j), drop_thr) ? xv * keep_scale : 0.f;
-          float xh = (b.get(j) + xv - mean) * rstd;
-          float dyv = pad ? 0.f : g.get(j);
-          float dh = dyv * gamma[vi * VN + j];
-          xhat[v][j] = xh;
-          dxh[v][j] = dh;
-          pg[v][j] += dyv * xh;
-          pb[v][j] += dyv;
-          s1 += dh;
-          s2 += dh * xh;
+        for (int v = 0; v < MAXV; ++v) {
+          const int vi = lane + v * 64;
+          if (vi < nvec) {
+            a[r][v].v = *(const raw_t*)(x + row * d + vi * VN);
+            b[r][v].v = *(const raw_t*)(res + row * d + vi * VN);
+            g[r][v].v = *(const raw_t*)(dy + row * d + vi * VN);
+          }
         }
       }
     }
-    const float c1 = wave_sum(s1) / (float)d, c2 = wave_sum(s2) / (float)d;
 #pragma unroll
-    for (int v = 0; v < MAXV; ++v) {
-      int vi = lane + v * 64;
-      if (vi < nvec) {
-        Vec16<T> o1, o2;
+    for (int r = 0; r < 2; ++r) {
+      const int64_t row = row0 + r * stride;
+      if (row >= T_rows) break;
+      const bool pad = pad_r[r];
+      const float mean = mean_r[r], rstd = rstd_r[r];
+      float xhat[MAXV][VN], dxh[MAXV][VN];
+      float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int j = 0; j < VN; ++j) {
-          float dz = rstd * (dxh[v][j] - c1 - xhat[v][j] * c2);
-          o1.set(j, dz);
-          float dxv = dz;
-          if (drop_thr) dxv = sk_keep(seed, (uint64_t)(row * d + vi * VN + j), drop_thr) ? dz * keep_scale : 0.f;
-          o2.set(j, dxv);
-          px[v][j] += dxv;
+      for (int v = 0; v < MAXV; ++v) {
+        const int vi = lane + v * 64;
+        if (vi < nvec)
+#pragma unroll
+          for (int j = 0; j < VN; ++j) {
+            float xv = a[r][v].get(j);
+            if (drop_thr) xv = sk_keep(seed, (uint64_t)(row * d + vi * VN + j), drop_thr) ? xv * keep_scale : 0.f;
+            const float xh = (b[r][v].get(j) + xv - mean) * rstd;
+            const float dyv = pad ? 0.f : g[r][v].get(j);
+            const float dh = dyv * gm[v][j];
+            xhat[v][j] = xh;
+            dxh[v][j] = dh;
+            pg[v][j] += dyv * xh;
+            pb[v][j] += dyv;
+            s1 += dh;
+            s2 += dh * xh;
+          }
+      }
+      const float c1 = wave_sum(s1) / (float)d, c2 = wave_sum(s2) / (float)d;
+#pragma unroll
+      for (int v = 0; v < MAXV; ++v) {
+        const int vi = lane + v * 64;
+        if (vi < nvec) {
+          Vec16<T> o1, o2;
+#pragma unroll
+          for (int j = 0; j < VN; ++j) {
+            const float dz = rstd * (dxh[v][j] - c1 - xhat[v][j] * c2);
+            o1.set(j, dz);
+            float dxv = dz;
+            if (drop_thr) dxv = sk_keep(seed, (uint64_t)(row * d + vi * VN + j), drop_thr) ? dz * keep_scale : 0.f;
+            o2.set(j, dxv);
+            px[v][j] += dxv;
+          }
+          *(raw_t*)(dres + row * d + vi * VN) = o1.v;
+          if (dx != dres) *(raw_t*)(dx + row * d + vi * VN) = o2.v;
         }
-        *(decltype(o1.v)*)(dres + row * d + vi * VN) = o1.v;
-        if (dx != dres) *(decltype(o2.v)*)(dx + row * d + vi * VN) = o2.v;
       }
     }
   }
   // block reduction of the parameter-gradient partials
 #pragma unroll
   for (int v = 0; v < MAXV; ++v) {
-    int vi = lane + v * 64;
+    const int vi = lane + v * 64;
     if (vi < nvec)
 #pragma unroll
       for (int j = 0; j < VN; ++j) {
@@ -170,7 +214,7 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const T* __restrict__ d
   __syncthreads();
   const int nd = LN_NPART * d;
   for (int i = threadIdx.x; i < nd; i += 256) {
-    float s = (red[i] + red[nd + i]) + (red[2 * nd + i] + red[3 * nd + i]);
+    const float s = (red[i] + red[nd + i]) + (red[2 * nd + i] + red[3 * nd + i]);
     partial[(int64_t)blockIdx.x * nd + i] = s;
   }
 }
@@ -216,16 +260,21 @@ extern "C" int skhip_add_ln_fwd(const void* x, const void* res, const float* gam
   SK_CHECK_ARG(p_drop >= 0.f && p_drop < 1.f, "skhip_add_ln_fwd: p_drop=%f", p_drop);
   if (T == 0) return SK_OK;
   SK_CHECK_ARG(x && res && gamma && beta && y && mean && rstd, "skhip_add_ln_fwd: null pointer");
-  int64_t blocks = (T + 3) / 4;
+  int64_t blocks = (T + 7) / 8;  // two rows per wave per pass
   if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
   uint32_t thr = sk_drop_threshold(p_drop);
   float ks = 1.0f / (1.0f - p_drop);
-  if (dtype == SK_BF16)
-    hipLaunchKernelGGL((add_ln_fwd_kernel<bf16_t>), dim3((unsigned)blocks), dim3(256), 0, stream, (const bf16_t*)x,
-                       (const bf16_t*)res, gamma, beta, row_pad, (bf16_t*)y, mean, rstd, T, d, eps, thr, ks, seed);
-  else
-    hipLaunchKernelGGL((add_ln_fwd_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, stream, (const float*)x,
-                       (const float*)res, gamma, beta, row_pad, (float*)y, mean, rstd, T, d, eps, thr, ks, seed);
+#define LN_FWD(TT, MV)                                                                                          \
+  hipLaunchKernelGGL((add_ln_fwd_kernel<TT, MV>), dim3((unsigned)blocks), dim3(256), 0, stream, (const TT*)x,   \
+                     (const TT*)res, gamma, beta, row_pad, (TT*)y, mean, rstd, T, d, eps, thr, ks, seed)
+  const int nvl = (d / (dtype == SK_BF16 ? 8 : 4) + 63) / 64;  // 16-byte vectors per lane
+  if (dtype == SK_BF16) {
+    if (nvl <= 1) LN_FWD(bf16_t, 1); else if (nvl <= 2) LN_FWD(bf16_t, 2); else LN_FWD(bf16_t, 4);
+  } else {
+    if (nvl <= 2) LN_FWD(float, 2); else if (nvl <= 4) LN_FWD(float, 4); else LN_FWD(float, 8);
+  }
+#undef LN_FWD
   SK_CHECK_LAUNCH("skhip_add_ln_fwd");
   return SK_OK;
 }
@@ -243,20 +292,23 @@ extern "C" int skhip_add_ln_bwd(const void* dy, const void* x, const void* res, 
   SK_CHECK_ARG(dy && x && res && gamma && mean && rstd && dx && dres && dgamma && dbeta && partial_ws,
                "skhip_add_ln_bwd: null pointer");
   SK_CHECK_ARG(p_drop == 0.f || dx != dres, "skhip_add_ln_bwd: dx may alias dres only without dropout");
-  int64_t blocks = (T + 3) / 4;
+  int64_t blocks = (T + 7) / 8;  // two rows per wave per pass
   if (blocks > LN_MAX_BLOCKS) blocks = LN_MAX_BLOCKS;
   if (blocks < 1) blocks = 1;
   uint32_t thr = sk_drop_threshold(p_drop);
   float ks = 1.0f / (1.0f - p_drop);
   size_t smem = (size_t)4 * LN_NPART * d * sizeof(float);
-  if (dtype == SK_BF16)
-    hipLaunchKernelGGL((add_ln_bwd_kernel<bf16_t>), dim3((unsigned)blocks), dim3(256), smem, stream, (const bf16_t*)dy,
-                       (const bf16_t*)x, (const bf16_t*)res, gamma, row_pad, mean, rstd, (bf16_t*)dx, (bf16_t*)dres,
-                       partial_ws, T, d, thr, ks, seed);
-  else
-    hipLaunchKernelGGL((add_ln_bwd_kernel<float>), dim3((unsigned)blocks), dim3(256), smem, stream, (const float*)dy,
-                       (const float*)x, (const float*)res, gamma, row_pad, mean, rstd, (float*)dx, (float*)dres,
-                       partial_ws, T, d, thr, ks, seed);
+#define LN_BWD(TT, MV)                                                                                            \
+  hipLaunchKernelGGL((add_ln_bwd_kernel<TT, MV>), dim3((unsigned)blocks), dim3(256), smem, stream, (const TT*)dy, \
+                     (const TT*)x, (const TT*)res, gamma, row_pad, mean, rstd, (TT*)dx, (TT*)dres, partial_ws, T, \
+                     d, thr, ks, seed)
+  const int nvl = (d / (dtype == SK_BF16 ? 8 : 4) + 63) / 64;  // 16-byte vectors per lane
+  if (dtype == SK_BF16) {
+    if (nvl <= 1) LN_BWD(bf16_t, 1); else if (nvl <= 2) LN_BWD(bf16_t, 2); else LN_BWD(bf16_t, 4);
+  } else {
+    if (nvl <= 2) LN_BWD(float, 2); else if (nvl <= 4) LN_BWD(float, 4); else LN_BWD(float, 8);
+  }
+#undef LN_BWD
   SK_CHECK_LAUNCH("skhip_add_ln_bwd");
   hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((LN_NPART * d + 63) / 64), dim3(256), 0, stream, partial_ws, dgamma,
                      dbeta, dx_colsum, d, (int)blocks, accumulate);

@@ -83,11 +83,25 @@ __global__ __launch_bounds__(256) void xent_kernel(const T* __restrict__ logits,
       else se += sk_exp<T>(v - mx);
     };
     if (vec_ok) {
+      // one rescale of the running sum per 16-byte vector instead of a branch per element
       for (int64_t c = (int64_t)threadIdx.x * VN; c < V; c += 256 * VN) {
         Vec16<T> a;
         a.v = *(const decltype(a.v)*)(x + c);
+        float v[VN];
+        float vm = -INFINITY;
 #pragma unroll
-        for (int j = 0; j < VN; ++j) visit(a.get(j), (int)(c + j));
+        for (int j = 0; j < VN; ++j) {
+          v[j] = a.get(j) * logit_scale;
+          sx += v[j];
+          if (v[j] > amv) { amv = v[j]; am = (int)(c + j); }
+          vm = fmaxf(vm, v[j]);
+        }
+        const float nm = fmaxf(mx, vm);
+        float part = 0.f;
+#pragma unroll
+        for (int j = 0; j < VN; ++j) part += sk_exp<T>(v[j] - nm);
+        se = se * sk_exp<T>(mx - nm) + part;  // mx = -inf on the first vector: exp(-inf) = 0 and se = 0
+        mx = nm;
       }
     } else {
       for (int64_t c = threadIdx.x; c < V; c += 256) visit(Cvt<T>::to_f32(x[c]), (int)c);

@@ -85,6 +85,30 @@ def test_gemm_splitk_wgrad(L, dtype):
     assert torch.equal(outs[0], outs[1]), "split-K must be bitwise reproducible"
 
 
+@pytest.mark.parametrize("env", [{"SKHIP_GEMM_BIG": "1"}, {"SKHIP_GEMM_BIG": "0", "SKHIP_GEMM_STAGED": "0"},
+                                 {"SKHIP_GEMM_BIG": "0", "SKHIP_GEMM_STAGED": "1"}])
+def test_gemm_bf16_kernel_variants(L, env):
+    """Every bf16 kernel variant (256x256 direct-to-LDS, 128x128 direct-to-LDS, 128x128 register
+    staged), forced through the library's environment switches, on ragged NT shapes with an
+    epilogue, a K tail and split-K."""
+    import os
+    g = torch.Generator().manual_seed(11)
+    old = {k: os.environ.get(k) for k in ("SKHIP_GEMM_BIG", "SKHIP_GEMM_STAGED")}
+    os.environ.update(env)
+    try:
+        for (M, N, K) in [(256, 256, 32), (700, 520, 200), (1000, 264, 1096), (513, 8, 72), (3, 1000, 8)]:
+            A, B = rnd((M, K), torch.bfloat16, g), rnd((N, K), torch.bfloat16, g)
+            bias = torch.randn(N, generator=g)
+            ref = torch.relu(A.double() @ B.double().t() + bias.double())
+            out = L.gemm(L.GEMM_NT, A.to(DEV), B.to(DEV), M, N, K, K, K, bias=bias.to(DEV), epilogue=L.EPI_RELU)
+            assert rel_err(out, ref) <= BF16_RTOL, (env, M, N, K)
+            out32 = L.gemm(L.GEMM_NT, A.to(DEV), B.to(DEV), M, N, K, K, K, out_dtype=torch.float32, split_k=False)
+            assert rel_err(out32, A.double() @ B.double().t()) <= 1e-5, (env, M, N, K)
+    finally:
+        for k, v in old.items():
+            os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+
+
 def test_colsum(L):
     g = torch.Generator().manual_seed(3)
     for dtype in (torch.float32, torch.bfloat16):

@@ -1,0 +1,65 @@
+"""A/B of the bf16 GEMM kernels on the Transformer-base training shapes, interleaved rounds in
+one process (GPU box).  Variants are selected through the library's environment switches.
+Also checks each variant against torch.matmul in fp32 on the same operands."""
+import os, sys
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from specialk_amd import _lib as L
+
+T, d, F, V = 33280, 512, 2048, 35000
+SHAPES = [
+    ("fwd  NT T x512 x512", 0, T, d, d, torch.bfloat16),
+    ("ffn1 NT T x2048x512", 0, T, F, d, torch.bfloat16),
+    ("ffn2 NT T x512 x2048", 0, T, d, F, torch.bfloat16),
+    ("gen  NT T x35000x512", 0, T, V, d, torch.bfloat16),
+    ("packed NT 25472x512x512", 0, 25472, d, d, torch.bfloat16),
+    ("packed NT 25472x2048x512", 0, 25472, F, d, torch.bfloat16),
+    ("dgrad NN T x512 x512", 1, T, d, d, torch.bfloat16),
+    ("dgrad NN T x2048x512", 1, T, F, d, torch.bfloat16),
+    ("dgrad NN T x512 x2048", 1, T, d, F, torch.bfloat16),
+    ("wgrad TN 512 x512 xT", 2, d, d, T, torch.float32),
+    ("wgrad TN 2048x512 xT", 2, F, d, T, torch.float32),
+    ("wgrad TN 512 x2048xT", 2, d, F, T, torch.float32),
+]
+VARIANTS = [("small", {"SKHIP_GEMM_BIG": "0"}), ("big", {"SKHIP_GEMM_BIG": "1"})]
+only = sys.argv[1] if len(sys.argv) > 1 else ""
+dev = "cuda"
+g = torch.Generator(device=dev).manual_seed(0)
+for name, layout, M, N, K, odt in SHAPES:
+    if only and only not in name:
+        continue
+    A = torch.randn((K, M) if layout == 2 else (M, K), device=dev, generator=g).to(torch.bfloat16)
+    B = torch.randn((N, K) if layout == 0 else (K, N), device=dev, generator=g).to(torch.bfloat16)
+    out = torch.empty((M, N), dtype=odt, device=dev)
+    run = lambda: L.gemm(layout, A, B, M, N, K, A.shape[1], B.shape[1], out=out, ldc=N)
+    rows = slice(0, min(M, 1024))
+    a32 = (A.float().t() if layout == 2 else A.float())
+    b32 = (B.float().t() if layout == 0 else B.float())
+    ref_head = a32[rows] @ b32[:, :2048]
+    ref_tail = a32[-300:] @ b32[:, -300:]
+    times = {v: [] for v, _ in VARIANTS}
+    errs = {}
+    for rnd in range(5):
+        for v, env in VARIANTS:
+            os.environ.update(env)
+            if rnd == 0:
+                out.zero_()
+                run()
+                torch.cuda.synchronize()
+                e1 = (out[rows, :2048].float() - ref_head).abs().max().item() / ref_head.abs().max().item()
+                e2 = (out[-300:, -300:].float() - ref_tail).abs().max().item() / ref_tail.abs().max().item()
+                errs[v] = max(e1, e2)
+            e0, e1_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                run()
+            e1_.record()
+            torch.cuda.synchronize()
+            times[v].append(e0.elapsed_time(e1_) * 1e3 / 5)
+    fl = 2.0 * M * N * K
+    line = f"{name:28s}"
+    for v, _ in VARIANTS:
+        t = sorted(times[v])
+        line += f" | {v}: med {t[2]:8.1f} us min {t[0]:8.1f} us {fl / t[2] / 1e6:7.1f} TF err {errs[v]:.1e}"
+    print(line, flush=True)
