@@ -77,6 +77,9 @@ def build(cfg, dtype, device):
     return m, opt
 
 
+PACKED = True  # run the network on the batch without its padding rows (--padded turns it off)
+
+
 def train_step(m, opt, batch, reducer):
     from specialk_amd import ops
     src_seq, src_pos, tgt_seq, tgt_pos = batch
@@ -84,8 +87,12 @@ def train_step(m, opt, batch, reducer):
         reducer.zero_grad()
     else:
         opt.zero_grad()
-    pred = m(src_seq, src_pos, tgt_seq, tgt_pos)
-    loss, stats = ops.xent(pred.view(-1, pred.size(2)), tgt_seq[:, 1:], True, unit_grad=True)
+    if PACKED:  # sentence lengths are derived from the ids on the device inside the timed step
+        pred, gold = m.forward_packed(src_seq, src_pos, tgt_seq, tgt_pos)
+        loss, stats = ops.xent(pred, gold, True, unit_grad=True)
+    else:
+        pred = m(src_seq, src_pos, tgt_seq, tgt_pos)
+        loss, stats = ops.xent(pred.view(-1, pred.size(2)), tgt_seq[:, 1:], True, unit_grad=True)
     loss.backward()
     if reducer is not None:
         reducer.finish()
@@ -127,7 +134,7 @@ def gemm_roofline(m, opt, batch, steps):
     n = len(records)
     return dict(bound="mfma", achieved=round(flops / (ms * 1e-3) / 1e12, 2), peak=MFMA_BF16_PEAK_TFLOPS,
                 unit="TFLOP/s", frac=round(flops / (ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4), traffic=None,
-                kernel="b16::gemm_kernel (bf16 MFMA GEMM, all layouts)", launches_per_step=n // steps,
+                kernel="b16g/b16/b16x::gemm_kernel (bf16 MFMA GEMMs, all layouts)", launches_per_step=n // steps,
                 avg_launch_us=round(ms * 1e3 / n, 2), avg_algorithmic_gflop_per_launch=round(flops / n / 1e9, 3))
 
 
@@ -199,6 +206,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--padded", action="store_true", help="keep padding rows (the reference's tensor shapes)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -215,6 +223,8 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     cfg = CONFIGS[args.config]
+    global PACKED
+    PACKED = not args.padded
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     m, opt = build(cfg, dtype, device)
     from specialk_amd import ops
@@ -263,7 +273,7 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": cfg["desc"], "config_name": args.config, "per_gpu_sentences": cfg["batch"],
-                       "target_tokens_per_step": int(tokens / args.steps), "label_smoothing": True, "dropout": 0.1,
+                       "target_tokens_per_step": int(tokens / args.steps), "padding_rows": "skipped (packed)" if PACKED else "computed", "label_smoothing": True, "dropout": 0.1,
                        "optimizer": "Adam(0.9,0.98,1e-9)+Noam(4000)", "parallelism": f"dp{world}"},
         }
     if world > 1:

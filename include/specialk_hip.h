@@ -106,6 +106,29 @@ int skhip_attn_bwd(const void* Q, const void* K, const void* V, const void* O, c
                    float scale, int causal, float p_drop, uint64_t seed,
                    int dtype, void* stream);
 
+/* Variable-length ("packed") batches: the rows of batch b are rows q_offsets[b] ..
+ * q_offsets[b+1]-1 of Q / O / dQ and k_offsets[b] .. k_offsets[b+1]-1 of K / V / dK / dV
+ * (int32 [B+1], device memory), with no padding rows between sentences, so key padding
+ * (lib/transformer/Models.py:49-57) is implied by the lengths; max_Lq / max_Lk are the longest
+ * sequences of the batch.  LSE and delta_ws stay [B][h][max_Lq]; entries of rows beyond a
+ * sentence's length are not written.  Otherwise as skhip_attn_fwd / skhip_attn_bwd (which have
+ * no counterpart of their own in the reference either: the reference pads).              */
+int skhip_attn_varlen_fwd(const void* Q, const void* K, const void* V, void* O, float* LSE,
+                          const int32_t* q_offsets, const int32_t* k_offsets,
+                          int B, int n_head, int max_Lq, int max_Lk, int dk, int dv,
+                          int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
+                          float scale, int causal, float p_drop, uint64_t seed,
+                          int dtype, void* stream);
+
+int skhip_attn_varlen_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO,
+                          const float* LSE, void* dQ, void* dK, void* dV, float* delta_ws,
+                          const int32_t* q_offsets, const int32_t* k_offsets,
+                          int B, int n_head, int max_Lq, int max_Lk, int dk, int dv,
+                          int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
+                          int64_t lddq, int64_t lddk, int64_t lddv,
+                          float scale, int causal, float p_drop, uint64_t seed,
+                          int dtype, void* stream);
+
 /* ---- residual + dropout + LayerNorm + pad-row zeroing --------------------------------
  * y = LayerNorm(res + dropout_p(x)) * gamma + beta, rows with row_pad != 0 set to 0.
  * Replaces `self.layer_norm(self.dropout(out) + residual)` (SubLayers.py:62-63,83-84) and

@@ -20,7 +20,7 @@ LIB_PATH = os.path.join(_HERE, "libspecialk_hip.so")
 # every symbol include/specialk_hip.h declares
 EXPORTS = [
     "skhip_version", "skhip_last_error", "skhip_init", "skhip_gemm", "skhip_colsum", "skhip_attn_fwd",
-    "skhip_attn_bwd", "skhip_add_ln_fwd", "skhip_add_ln_bwd_ws_floats", "skhip_add_ln_bwd", "skhip_embed_fwd",
+    "skhip_attn_bwd", "skhip_attn_varlen_fwd", "skhip_attn_varlen_bwd", "skhip_add_ln_fwd", "skhip_add_ln_bwd_ws_floats", "skhip_add_ln_bwd", "skhip_embed_fwd",
     "skhip_embed_bwd", "skhip_xent_fwd_bwd", "skhip_adam_multi", "skhip_cast_multi", "skhip_convert",
     "skhip_decode_attn", "skhip_beam_topk_ws_bytes", "skhip_beam_topk", "skhip_gather_rows",
 ]
@@ -51,6 +51,8 @@ def load():
     lib.skhip_colsum.argtypes = [c_p, c_p, c_i64, c_i64, c_i64, c_int, c_int, c_p, c_i64, c_p]
     lib.skhip_attn_fwd.argtypes = [c_p] * 8 + [c_int] * 6 + [c_i64] * 4 + [c_f32, c_int, c_f32, c_u64, c_int, c_p]
     lib.skhip_attn_bwd.argtypes = [c_p] * 12 + [c_int] * 6 + [c_i64] * 7 + [c_f32, c_int, c_f32, c_u64, c_int, c_p]
+    lib.skhip_attn_varlen_fwd.argtypes = [c_p] * 7 + [c_int] * 6 + [c_i64] * 4 + [c_f32, c_int, c_f32, c_u64, c_int, c_p]
+    lib.skhip_attn_varlen_bwd.argtypes = [c_p] * 12 + [c_int] * 6 + [c_i64] * 7 + [c_f32, c_int, c_f32, c_u64, c_int, c_p]
     lib.skhip_add_ln_fwd.argtypes = [c_p] * 8 + [c_i64, c_int, c_f32, c_f32, c_u64, c_int, c_p]
     lib.skhip_add_ln_bwd.argtypes = [c_p] * 13 + [c_i64, c_int, c_f32, c_u64, c_int, c_int, c_p]
     lib.skhip_embed_fwd.argtypes = [c_p] * 5 + [c_i64, c_int, c_i64, c_i64, c_int, c_p]
@@ -143,8 +145,15 @@ def colsum(X, M, N, ldx, out=None, accumulate=False):
 
 # --------------------------------------------------------------------------- attention
 def attn_fwd(Q, K, V, O, LSE, B, H, Lq, Lk, dk, dv, ldq, ldk, ldv, ldo, scale, key_pad=None, dense_mask=None,
-             causal=False, p_drop=0.0, seed=0, P_out=None):
+             causal=False, p_drop=0.0, seed=0, P_out=None, q_off=None, k_off=None):
+    """q_off / k_off (int32 [B+1] row offsets) select the packed form; Lq, Lk are then the maxima."""
     lib = load()
+    if q_off is not None:
+        assert key_pad is None and dense_mask is None and P_out is None and q_off.dtype == torch.int32
+        rc = lib.skhip_attn_varlen_fwd(_ptr(Q), _ptr(K), _ptr(V), _ptr(O), _ptr(LSE), _ptr(q_off), _ptr(k_off), B, H,
+                                       Lq, Lk, dk, dv, ldq, ldk, ldv, ldo, float(scale), int(causal), float(p_drop),
+                                       int(seed), dcode(Q.dtype), _stream())
+        return _check(rc, "skhip_attn_varlen_fwd")
     rc = lib.skhip_attn_fwd(_ptr(Q), _ptr(K), _ptr(V), _ptr(O), _ptr(LSE), _ptr(P_out), _ptr(key_pad),
                             _ptr(dense_mask), B, H, Lq, Lk, dk, dv, ldq, ldk, ldv, ldo, float(scale), int(causal),
                             float(p_drop), int(seed), dcode(Q.dtype), _stream())
@@ -152,8 +161,15 @@ def attn_fwd(Q, K, V, O, LSE, B, H, Lq, Lk, dk, dv, ldq, ldk, ldv, ldo, scale, k
 
 
 def attn_bwd(Q, K, V, O, dO, LSE, dQ, dK, dV, delta, B, H, Lq, Lk, dk, dv, ldq, ldk, ldv, ldo, lddq, lddk, lddv,
-             scale, key_pad=None, dense_mask=None, causal=False, p_drop=0.0, seed=0):
+             scale, key_pad=None, dense_mask=None, causal=False, p_drop=0.0, seed=0, q_off=None, k_off=None):
     lib = load()
+    if q_off is not None:
+        assert key_pad is None and dense_mask is None and q_off.dtype == torch.int32
+        rc = lib.skhip_attn_varlen_bwd(_ptr(Q), _ptr(K), _ptr(V), _ptr(O), _ptr(dO), _ptr(LSE), _ptr(dQ), _ptr(dK),
+                                       _ptr(dV), _ptr(delta), _ptr(q_off), _ptr(k_off), B, H, Lq, Lk, dk, dv, ldq, ldk,
+                                       ldv, ldo, lddq, lddk, lddv, float(scale), int(causal), float(p_drop), int(seed),
+                                       dcode(Q.dtype), _stream())
+        return _check(rc, "skhip_attn_varlen_bwd")
     rc = lib.skhip_attn_bwd(_ptr(Q), _ptr(K), _ptr(V), _ptr(O), _ptr(dO), _ptr(LSE), _ptr(dQ), _ptr(dK), _ptr(dV),
                             _ptr(delta), _ptr(key_pad), _ptr(dense_mask), B, H, Lq, Lk, dk, dv, ldq, ldk, ldv, ldo,
                             lddq, lddk, lddv, float(scale), int(causal), float(p_drop), int(seed), dcode(Q.dtype),

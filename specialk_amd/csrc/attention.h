@@ -12,6 +12,8 @@ struct AttnParams {
   float* delta;
   const uint8_t* key_pad;
   const uint8_t* dense;
+  const int32_t* q_off;  // packed ("varlen") batches: rows of batch b are q_off[b] .. q_off[b+1]-1
+  const int32_t* k_off;  //   of Q/O/dQ resp. K/V/dK/dV; NULL = padded (B, L) rows.  Lq, Lk = maxima.
   int B, H, Lq, Lk, dk, dv;
   int64_t ldq, ldk, ldv, ldo, lddq, lddk, lddv;
   float scale;
@@ -26,8 +28,25 @@ __device__ __forceinline__ float ld(const void* base, int64_t off) { return Cvt<
 template <typename T>
 __device__ __forceinline__ void st(void* base, int64_t off, float v) { ((T*)base)[off] = Cvt<T>::from_f32(v); }
 
-__device__ __forceinline__ bool masked(const AttnParams& p, int b, int i, int j) {
-  if (j >= p.Lk || i >= p.Lq) return true;
+// First row and length of batch b's query and key sequences.
+struct Seq {
+  int64_t qbase, kbase;
+  int Lq, Lk;
+};
+__device__ __forceinline__ Seq seq_of(const AttnParams& p, int b) {
+  Seq s;
+  if (p.q_off) {
+    s.qbase = p.q_off[b]; s.Lq = p.q_off[b + 1] - p.q_off[b];
+    s.kbase = p.k_off[b]; s.Lk = p.k_off[b + 1] - p.k_off[b];
+  } else {
+    s.qbase = (int64_t)b * p.Lq; s.Lq = p.Lq;
+    s.kbase = (int64_t)b * p.Lk; s.Lk = p.Lk;
+  }
+  return s;
+}
+
+__device__ __forceinline__ bool masked(const AttnParams& p, const Seq& sq, int b, int i, int j) {
+  if (j >= sq.Lk || i >= sq.Lq) return true;
   if (p.key_pad && p.key_pad[(int64_t)b * p.Lk + j]) return true;
   if (p.causal && j > i) return true;
   if (p.dense && p.dense[((int64_t)b * p.Lq + i) * p.Lk + j]) return true;

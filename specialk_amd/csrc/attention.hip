@@ -78,23 +78,26 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
   float* qs = Vs + TILE * (p.dv + 1);           // [OWN][dk+1]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int b = blockIdx.z, h = blockIdx.y, i0 = blockIdx.x * OWN;
-  const int64_t qrow0 = (int64_t)b * p.Lq, krow0 = (int64_t)b * p.Lk;
+  const Seq sq = seq_of(p, b);
+  const int Lq = sq.Lq, Lk = sq.Lk;
+  if (i0 >= Lq) return;  // block-uniform (shorter sentence of a packed batch)
+  const int64_t qrow0 = sq.qbase, krow0 = sq.kbase;
 
-  stage<T>(qs, p.Q, p.ldq, qrow0, i0, p.Lq, OWN, h * p.dk, p.dk, p.scale);
+  stage<T>(qs, p.Q, p.ldq, qrow0, i0, Lq, OWN, h * p.dk, p.dk, p.scale);
   float m[4], l[4], acc[4][2];
 #pragma unroll
   for (int r = 0; r < 4; ++r) { m[r] = -INFINITY; l[r] = 0.f; acc[r][0] = acc[r][1] = 0.f; }
 
-  for (int j0 = 0; j0 < p.Lk; j0 += TILE) {
+  for (int j0 = 0; j0 < Lk; j0 += TILE) {
     __syncthreads();
-    stage<T>(Ks, p.K, p.ldk, krow0, j0, p.Lk, TILE, h * p.dk, p.dk, 1.f);
-    stage<T>(Vs, p.V, p.ldv, krow0, j0, p.Lk, TILE, h * p.dv, p.dv, 1.f);
+    stage<T>(Ks, p.K, p.ldk, krow0, j0, Lk, TILE, h * p.dk, p.dk, 1.f);
+    stage<T>(Vs, p.V, p.ldv, krow0, j0, Lk, TILE, h * p.dv, p.dv, 1.f);
     __syncthreads();
     const int j = j0 + lane;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int i = i0 + wave * 4 + r;
-      float s = masked(p, b, i, j) ? -INFINITY : dot_row(qs + (wave * 4 + r) * (p.dk + 1), Ks + lane * (p.dk + 1), p.dk);
+      float s = masked(p, sq, b, i, j) ? -INFINITY : dot_row(qs + (wave * 4 + r) * (p.dk + 1), Ks + lane * (p.dk + 1), p.dk);
       float mn = fmaxf(m[r], wave_max(s));
       float pr = 0.f, alpha = 1.f;
       if (mn != -INFINITY) {
@@ -111,7 +114,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int i = i0 + wave * 4 + r;
-    if (i < p.Lq) {
+    if (i < Lq) {
       float inv = 1.0f / l[r];  // l == 0 (fully masked row) -> 0 * inf = NaN, as torch's softmax gives
       int64_t off = (qrow0 + i) * p.ldo + h * p.dv;
       if (lane < p.dv) st<T>(p.Oout, off + lane, acc[r][0] * inv);
@@ -120,18 +123,18 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
     }
   }
   if (p.P_out) {  // optional: materialise the (dropped-out) probabilities, head-major like the reference
-    for (int j0 = 0; j0 < p.Lk; j0 += TILE) {
+    for (int j0 = 0; j0 < Lk; j0 += TILE) {
       __syncthreads();
-      stage<T>(Ks, p.K, p.ldk, krow0, j0, p.Lk, TILE, h * p.dk, p.dk, 1.f);
+      stage<T>(Ks, p.K, p.ldk, krow0, j0, Lk, TILE, h * p.dk, p.dk, 1.f);
       __syncthreads();
       const int j = j0 + lane;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int i = i0 + wave * 4 + r;
-        if (i < p.Lq && j < p.Lk) {
+        if (i < Lq && j < Lk) {
           float pr;
           if (l[r] == 0.f) pr = NAN;
-          else if (masked(p, b, i, j)) pr = 0.f;
+          else if (masked(p, sq, b, i, j)) pr = 0.f;
           else pr = expf(dot_row(qs + (wave * 4 + r) * (p.dk + 1), Ks + lane * (p.dk + 1), p.dk) - m[r]) / l[r];
           pr = keep(p, b, h, i, j) ? pr * p.keep_scale : 0.f;
           st<T>(p.P_out, (((int64_t)h * p.B + b) * p.Lq + i) * p.Lk + j, pr);
@@ -150,7 +153,9 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(AttnParams p) {
     int i = (int)(idx % p.Lq);
     int h = (int)((idx / p.Lq) % p.H);
     int b = (int)(idx / ((int64_t)p.Lq * p.H));
-    int64_t off = ((int64_t)b * p.Lq + i) * p.ldo + h * p.dv;
+    const Seq sq = seq_of(p, b);
+    if (i >= sq.Lq) continue;  // wave-uniform
+    int64_t off = (sq.qbase + i) * p.ldo + h * p.dv;
     float s = 0.f;
     for (int c = lane; c < p.dv; c += 64) s += ld<T>(p.dO, off + c) * ld<T>(p.O, off + c);
     s = wave_sum(s);
@@ -168,28 +173,31 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
   float* dos = qs + OWN * (p.dk + 1);           // [OWN][dv+1]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int b = blockIdx.z, h = blockIdx.y, i0 = blockIdx.x * OWN;
-  const int64_t qrow0 = (int64_t)b * p.Lq, krow0 = (int64_t)b * p.Lk;
-  stage<T>(qs, p.Q, p.ldq, qrow0, i0, p.Lq, OWN, h * p.dk, p.dk, p.scale);
-  stage<T>(dos, p.dO, p.ldo, qrow0, i0, p.Lq, OWN, h * p.dv, p.dv, 1.f);
+  const Seq sq = seq_of(p, b);
+  const int Lq = sq.Lq, Lk = sq.Lk;
+  if (i0 >= Lq) return;  // block-uniform
+  const int64_t qrow0 = sq.qbase, krow0 = sq.kbase;
+  stage<T>(qs, p.Q, p.ldq, qrow0, i0, Lq, OWN, h * p.dk, p.dk, p.scale);
+  stage<T>(dos, p.dO, p.ldo, qrow0, i0, Lq, OWN, h * p.dv, p.dv, 1.f);
   float lse[4], dl[4], acc[4][2];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int i = i0 + wave * 4 + r;
-    int64_t si = ((int64_t)b * p.H + h) * p.Lq + (i < p.Lq ? i : 0);
+    int64_t si = ((int64_t)b * p.H + h) * p.Lq + (i < Lq ? i : 0);
     lse[r] = p.LSE[si]; dl[r] = p.delta[si];
     acc[r][0] = acc[r][1] = 0.f;
   }
-  for (int j0 = 0; j0 < p.Lk; j0 += TILE) {
+  for (int j0 = 0; j0 < Lk; j0 += TILE) {
     __syncthreads();
-    stage<T>(Ks, p.K, p.ldk, krow0, j0, p.Lk, TILE, h * p.dk, p.dk, 1.f);
-    stage<T>(Vs, p.V, p.ldv, krow0, j0, p.Lk, TILE, h * p.dv, p.dv, 1.f);
+    stage<T>(Ks, p.K, p.ldk, krow0, j0, Lk, TILE, h * p.dk, p.dk, 1.f);
+    stage<T>(Vs, p.V, p.ldv, krow0, j0, Lk, TILE, h * p.dv, p.dv, 1.f);
     __syncthreads();
     const int j = j0 + lane;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int i = i0 + wave * 4 + r;
       float ds = 0.f;
-      if (!masked(p, b, i, j)) {
+      if (!masked(p, sq, b, i, j)) {
         float s = dot_row(qs + (wave * 4 + r) * (p.dk + 1), Ks + lane * (p.dk + 1), p.dk);
         float pr = expf(s - lse[r]);
         float dp = dot_row(dos + (wave * 4 + r) * (p.dv + 1), Vs + lane * (p.dv + 1), p.dv);
@@ -202,7 +210,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int i = i0 + wave * 4 + r;
-    if (i < p.Lq) {
+    if (i < Lq) {
       int64_t off = (qrow0 + i) * p.lddq + h * p.dk;
       if (lane < p.dk) st<T>(p.dQ, off + lane, acc[r][0]);
       if (lane + 64 < p.dk) st<T>(p.dQ, off + lane + 64, acc[r][1]);
@@ -220,25 +228,28 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
   float* vs = ks + OWN * (p.dk + 1);            // [OWN][dv+1]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int b = blockIdx.z, h = blockIdx.y, j0 = blockIdx.x * OWN;
-  const int64_t qrow0 = (int64_t)b * p.Lq, krow0 = (int64_t)b * p.Lk;
-  stage<T>(ks, p.K, p.ldk, krow0, j0, p.Lk, OWN, h * p.dk, p.dk, 1.f);
-  stage<T>(vs, p.V, p.ldv, krow0, j0, p.Lk, OWN, h * p.dv, p.dv, 1.f);
+  const Seq sq = seq_of(p, b);
+  const int Lq = sq.Lq, Lk = sq.Lk;
+  if (j0 >= Lk) return;  // block-uniform
+  const int64_t qrow0 = sq.qbase, krow0 = sq.kbase;
+  stage<T>(ks, p.K, p.ldk, krow0, j0, Lk, OWN, h * p.dk, p.dk, 1.f);
+  stage<T>(vs, p.V, p.ldv, krow0, j0, Lk, OWN, h * p.dv, p.dv, 1.f);
   float accK[4][2], accV[4][2];
 #pragma unroll
   for (int r = 0; r < 4; ++r) accK[r][0] = accK[r][1] = accV[r][0] = accV[r][1] = 0.f;
-  for (int i0 = 0; i0 < p.Lq; i0 += TILE) {
+  for (int i0 = 0; i0 < Lq; i0 += TILE) {
     __syncthreads();
-    stage<T>(Qs, p.Q, p.ldq, qrow0, i0, p.Lq, TILE, h * p.dk, p.dk, p.scale);
-    stage<T>(dOs, p.dO, p.ldo, qrow0, i0, p.Lq, TILE, h * p.dv, p.dv, 1.f);
+    stage<T>(Qs, p.Q, p.ldq, qrow0, i0, Lq, TILE, h * p.dk, p.dk, p.scale);
+    stage<T>(dOs, p.dO, p.ldo, qrow0, i0, Lq, TILE, h * p.dv, p.dv, 1.f);
     __syncthreads();
     const int i = i0 + lane;
-    int64_t si = ((int64_t)b * p.H + h) * p.Lq + (i < p.Lq ? i : 0);
+    int64_t si = ((int64_t)b * p.H + h) * p.Lq + (i < Lq ? i : 0);
     const float lse = p.LSE[si], dl = p.delta[si];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int j = j0 + wave * 4 + r;
       float pd = 0.f, ds = 0.f;
-      if (!masked(p, b, i, j)) {
+      if (!masked(p, sq, b, i, j)) {
         float s = dot_row(ks + (wave * 4 + r) * (p.dk + 1), Qs + lane * (p.dk + 1), p.dk);
         float pr = expf(s - lse);
         float dp = dot_row(vs + (wave * 4 + r) * (p.dv + 1), dOs + lane * (p.dv + 1), p.dv);
@@ -254,7 +265,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int j = j0 + wave * 4 + r;
-    if (j < p.Lk) {
+    if (j < Lk) {
       int64_t offk = (krow0 + j) * p.lddk + h * p.dk, offv = (krow0 + j) * p.lddv + h * p.dv;
       if (lane < p.dk) st<T>(p.dK, offk + lane, accK[r][0]);
       if (lane + 64 < p.dk) st<T>(p.dK, offk + lane + 64, accK[r][1]);
@@ -279,12 +290,10 @@ int check_common(const char* who, int B, int H, int Lq, int Lk, int dk, int dv, 
   return SK_OK;
 }
 
-}  // namespace
-
-extern "C" int skhip_attn_fwd(const void* Q, const void* K, const void* V, void* O, float* LSE, void* P_out,
-                              const uint8_t* key_pad, const uint8_t* dense_mask, int B, int n_head, int Lq, int Lk, int dk,
-                              int dv, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, float scale, int causal,
-                              float p_drop, uint64_t seed, int dtype, void* stream_) {
+int attn_fwd_impl(const void* Q, const void* K, const void* V, void* O, float* LSE, void* P_out,
+                  const uint8_t* key_pad, const uint8_t* dense_mask, const int32_t* q_off, const int32_t* k_off, int B,
+                  int n_head, int Lq, int Lk, int dk, int dv, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
+                  float scale, int causal, float p_drop, uint64_t seed, int dtype, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   int rc = check_common("skhip_attn_fwd", B, n_head, Lq, Lk, dk, dv, p_drop, dtype);
   if (rc) return rc;
@@ -292,7 +301,7 @@ extern "C" int skhip_attn_fwd(const void* Q, const void* K, const void* V, void*
   SK_CHECK_ARG(Q && K && V && O && LSE, "skhip_attn_fwd: null pointer");
   AttnParams p = {};
   p.Q = Q; p.K = K; p.V = V; p.Oout = O; p.LSE = LSE; p.P_out = P_out;
-  p.key_pad = key_pad; p.dense = dense_mask;
+  p.key_pad = key_pad; p.dense = dense_mask; p.q_off = q_off; p.k_off = k_off;
   p.B = B; p.H = n_head; p.Lq = Lq; p.Lk = Lk; p.dk = dk; p.dv = dv;
   p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo;
   p.scale = scale; p.causal = causal;
@@ -311,11 +320,11 @@ extern "C" int skhip_attn_fwd(const void* Q, const void* K, const void* V, void*
   return SK_OK;
 }
 
-extern "C" int skhip_attn_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* LSE,
-                              void* dQ, void* dK, void* dV, float* delta_ws, const uint8_t* key_pad,
-                              const uint8_t* dense_mask, int B, int n_head, int Lq, int Lk, int dk, int dv, int64_t ldq,
-                              int64_t ldk, int64_t ldv, int64_t ldo, int64_t lddq, int64_t lddk, int64_t lddv, float scale,
-                              int causal, float p_drop, uint64_t seed, int dtype, void* stream_) {
+int attn_bwd_impl(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* LSE,
+                  void* dQ, void* dK, void* dV, float* delta_ws, const uint8_t* key_pad, const uint8_t* dense_mask,
+                  const int32_t* q_off, const int32_t* k_off, int B, int n_head, int Lq, int Lk, int dk, int dv,
+                  int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t lddq, int64_t lddk, int64_t lddv,
+                  float scale, int causal, float p_drop, uint64_t seed, int dtype, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   int rc = check_common("skhip_attn_bwd", B, n_head, Lq, Lk, dk, dv, p_drop, dtype);
   if (rc) return rc;
@@ -324,7 +333,7 @@ extern "C" int skhip_attn_bwd(const void* Q, const void* K, const void* V, const
   AttnParams p = {};
   p.Q = Q; p.K = K; p.V = V; p.O = O; p.dO = dO; p.LSE = (float*)LSE; p.delta = delta_ws;
   p.dQ = dQ; p.dK = dK; p.dV = dV;
-  p.key_pad = key_pad; p.dense = dense_mask;
+  p.key_pad = key_pad; p.dense = dense_mask; p.q_off = q_off; p.k_off = k_off;
   p.B = B; p.H = n_head; p.Lq = Lq; p.Lk = Lk; p.dk = dk; p.dv = dv;
   p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo; p.lddq = lddq; p.lddk = lddk; p.lddv = lddv;
   p.scale = scale; p.causal = causal;
@@ -349,4 +358,43 @@ extern "C" int skhip_attn_bwd(const void* Q, const void* K, const void* V, const
   }
   SK_CHECK_LAUNCH("skhip_attn_bwd");
   return SK_OK;
+}
+
+}  // namespace
+
+extern "C" int skhip_attn_fwd(const void* Q, const void* K, const void* V, void* O, float* LSE, void* P_out,
+                              const uint8_t* key_pad, const uint8_t* dense_mask, int B, int n_head, int Lq, int Lk, int dk,
+                              int dv, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, float scale, int causal,
+                              float p_drop, uint64_t seed, int dtype, void* stream) {
+  return attn_fwd_impl(Q, K, V, O, LSE, P_out, key_pad, dense_mask, nullptr, nullptr, B, n_head, Lq, Lk, dk, dv, ldq, ldk,
+                       ldv, ldo, scale, causal, p_drop, seed, dtype, stream);
+}
+
+extern "C" int skhip_attn_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* LSE,
+                              void* dQ, void* dK, void* dV, float* delta_ws, const uint8_t* key_pad,
+                              const uint8_t* dense_mask, int B, int n_head, int Lq, int Lk, int dk, int dv, int64_t ldq,
+                              int64_t ldk, int64_t ldv, int64_t ldo, int64_t lddq, int64_t lddk, int64_t lddv, float scale,
+                              int causal, float p_drop, uint64_t seed, int dtype, void* stream) {
+  return attn_bwd_impl(Q, K, V, O, dO, LSE, dQ, dK, dV, delta_ws, key_pad, dense_mask, nullptr, nullptr, B, n_head, Lq, Lk,
+                       dk, dv, ldq, ldk, ldv, ldo, lddq, lddk, lddv, scale, causal, p_drop, seed, dtype, stream);
+}
+
+extern "C" int skhip_attn_varlen_fwd(const void* Q, const void* K, const void* V, void* O, float* LSE,
+                                     const int32_t* q_offsets, const int32_t* k_offsets, int B, int n_head, int max_Lq,
+                                     int max_Lk, int dk, int dv, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
+                                     float scale, int causal, float p_drop, uint64_t seed, int dtype, void* stream) {
+  SK_CHECK_ARG(q_offsets && k_offsets, "skhip_attn_varlen_fwd: null offsets");
+  return attn_fwd_impl(Q, K, V, O, LSE, nullptr, nullptr, nullptr, q_offsets, k_offsets, B, n_head, max_Lq, max_Lk, dk, dv,
+                       ldq, ldk, ldv, ldo, scale, causal, p_drop, seed, dtype, stream);
+}
+
+extern "C" int skhip_attn_varlen_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO,
+                                     const float* LSE, void* dQ, void* dK, void* dV, float* delta_ws,
+                                     const int32_t* q_offsets, const int32_t* k_offsets, int B, int n_head, int max_Lq,
+                                     int max_Lk, int dk, int dv, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
+                                     int64_t lddq, int64_t lddk, int64_t lddv, float scale, int causal, float p_drop,
+                                     uint64_t seed, int dtype, void* stream) {
+  SK_CHECK_ARG(q_offsets && k_offsets, "skhip_attn_varlen_bwd: null offsets");
+  return attn_bwd_impl(Q, K, V, O, dO, LSE, dQ, dK, dV, delta_ws, nullptr, nullptr, q_offsets, k_offsets, B, n_head, max_Lq,
+                       max_Lk, dk, dv, ldq, ldk, ldv, ldo, lddq, lddk, lddv, scale, causal, p_drop, seed, dtype, stream);
 }

@@ -94,10 +94,13 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(AttnParams p) {
   const int b = blockIdx.z, h = blockIdx.y;
   const int c = lane & 15, g = lane >> 4;
   const int q = blockIdx.x * 64 + wave * 16 + c;
-  const int qrow = min(q, p.Lq - 1);
-  const bf16_t* Q = (const bf16_t*)p.Q + ((int64_t)b * p.Lq + qrow) * p.ldq + h * D;
-  const bf16_t* K = (const bf16_t*)p.K + (int64_t)b * p.Lk * p.ldk + h * D;
-  const bf16_t* V = (const bf16_t*)p.V + (int64_t)b * p.Lk * p.ldv + h * D;
+  const Seq sq = seq_of(p, b);
+  const int Lq = sq.Lq, Lk = sq.Lk;
+  if ((int)blockIdx.x * 64 >= Lq) return;  // block-uniform (shorter sentence of a packed batch)
+  const int qrow = min(q, Lq - 1);
+  const bf16_t* Q = (const bf16_t*)p.Q + (sq.qbase + qrow) * p.ldq + h * D;
+  const bf16_t* K = (const bf16_t*)p.K + sq.kbase * p.ldk + h * D;
+  const bf16_t* V = (const bf16_t*)p.V + sq.kbase * p.ldv + h * D;
   bf16x8_t fq[D / 32];
 #pragma unroll
   for (int s = 0; s < D / 32; ++s) fq[s] = ld_frag_global(Q + 32 * s + 8 * g);
@@ -107,13 +110,13 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(AttnParams p) {
 #pragma unroll
   for (int t = 0; t < D / 16; ++t) o[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-  for (int j0 = 0; j0 < p.Lk; j0 += OT) {
+  for (int j0 = 0; j0 < Lk; j0 += OT) {
     __syncthreads();
-    stage_tile<D>(Ks, K, p.ldk, j0, p.Lk);
-    stage_tile<D>(Vs, V, p.ldv, j0, p.Lk);
+    stage_tile<D>(Ks, K, p.ldk, j0, Lk);
+    stage_tile<D>(Vs, V, p.ldv, j0, Lk);
     if (threadIdx.x < OT) {
       const int j = j0 + threadIdx.x;
-      kmask[threadIdx.x] = (j >= p.Lk) || (p.key_pad && p.key_pad[(int64_t)b * p.Lk + j]);
+      kmask[threadIdx.x] = (j >= Lk) || (p.key_pad && p.key_pad[(int64_t)b * p.Lk + j]);
     }
     __syncthreads();
     f32x4_t sc[4];
@@ -155,9 +158,9 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(AttnParams p) {
       o[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x_cols<D>(Vs, 16 * t, 1, lane), y1, o[t], 0, 0, 0);
     }
   }
-  if (q < p.Lq) {
+  if (q < Lq) {
     const float inv = 1.0f / l;  // fully masked row: 0 * inf = NaN, like the reference's softmax
-    bf16_t* O = (bf16_t*)p.Oout + ((int64_t)b * p.Lq + q) * p.ldo + h * D;
+    bf16_t* O = (bf16_t*)p.Oout + (sq.qbase + q) * p.ldo + h * D;
 #pragma unroll
     for (int t = 0; t < D / 16; ++t) {
       uint2 w;
@@ -180,13 +183,16 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(AttnParams p) {
   const int b = blockIdx.z, h = blockIdx.y;
   const int c = lane & 15, g = lane >> 4;
   const int q = blockIdx.x * 64 + wave * 16 + c;
-  const int qrow = min(q, p.Lq - 1);
-  const int64_t qoff = ((int64_t)b * p.Lq + qrow);
+  const Seq sq = seq_of(p, b);
+  const int Lq = sq.Lq, Lk = sq.Lk;
+  if ((int)blockIdx.x * 64 >= Lq) return;  // block-uniform
+  const int qrow = min(q, Lq - 1);
+  const int64_t qoff = sq.qbase + qrow;
   const bf16_t* Q = (const bf16_t*)p.Q + qoff * p.ldq + h * D;
   const bf16_t* dO = (const bf16_t*)p.dO + qoff * p.ldo + h * D;
   const bf16_t* O = (const bf16_t*)p.O + qoff * p.ldo + h * D;
-  const bf16_t* K = (const bf16_t*)p.K + (int64_t)b * p.Lk * p.ldk + h * D;
-  const bf16_t* V = (const bf16_t*)p.V + (int64_t)b * p.Lk * p.ldv + h * D;
+  const bf16_t* K = (const bf16_t*)p.K + sq.kbase * p.ldk + h * D;
+  const bf16_t* V = (const bf16_t*)p.V + sq.kbase * p.ldv + h * D;
   bf16x8_t fq[D / 32], fdo[D / 32];
   float dl = 0.f;
 #pragma unroll
@@ -200,19 +206,19 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(AttnParams p) {
   dl = quad_sum(dl);  // delta = rowsum(dO * O)
   const int64_t si = ((int64_t)b * p.H + h) * p.Lq + qrow;
   const float lse = p.LSE[si];
-  if (q < p.Lq && g == 0) p.delta[si] = dl;
+  if (q < Lq && g == 0) p.delta[si] = dl;
 
   f32x4_t dq[D / 16];
 #pragma unroll
   for (int t = 0; t < D / 16; ++t) dq[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-  for (int j0 = 0; j0 < p.Lk; j0 += OT) {
+  for (int j0 = 0; j0 < Lk; j0 += OT) {
     __syncthreads();
-    stage_tile<D>(Ks, K, p.ldk, j0, p.Lk);
-    stage_tile<D>(Vs, V, p.ldv, j0, p.Lk);
+    stage_tile<D>(Ks, K, p.ldk, j0, Lk);
+    stage_tile<D>(Vs, V, p.ldv, j0, Lk);
     if (threadIdx.x < OT) {
       const int j = j0 + threadIdx.x;
-      kmask[threadIdx.x] = (j >= p.Lk) || (p.key_pad && p.key_pad[(int64_t)b * p.Lk + j]);
+      kmask[threadIdx.x] = (j >= Lk) || (p.key_pad && p.key_pad[(int64_t)b * p.Lk + j]);
     }
     __syncthreads();
     f32x4_t ds[4];
@@ -227,7 +233,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(AttnParams p) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int jl = 16 * kt + 4 * g + r;
-        const bool msk = kmask[jl] || (p.causal && j0 + jl > q) || q >= p.Lq;
+        const bool msk = kmask[jl] || (p.causal && j0 + jl > q) || q >= Lq;
         float pr = msk ? 0.f : __expf(sc[r] * p.scale - lse);
         float dpv = dp[r];
         if (p.drop_thr) dpv = keep(p, b, h, q, j0 + jl) ? dpv * p.keep_scale : 0.f;
@@ -241,8 +247,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(AttnParams p) {
       dq[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x_cols<D>(Ks, 16 * t, 1, lane), y1, dq[t], 0, 0, 0);
     }
   }
-  if (q < p.Lq) {
-    bf16_t* out = (bf16_t*)p.dQ + ((int64_t)b * p.Lq + q) * p.lddq + h * D;
+  if (q < Lq) {
+    bf16_t* out = (bf16_t*)p.dQ + (sq.qbase + q) * p.lddq + h * D;
 #pragma unroll
     for (int t = 0; t < D / 16; ++t) {
       uint2 w;
@@ -264,29 +270,32 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(AttnParams p) {
   const int b = blockIdx.z, h = blockIdx.y;
   const int c = lane & 15, g = lane >> 4;
   const int j = blockIdx.x * 64 + wave * 16 + c;  // own key row
-  const int jrow = min(j, p.Lk - 1);
-  const bf16_t* K = (const bf16_t*)p.K + ((int64_t)b * p.Lk + jrow) * p.ldk + h * D;
-  const bf16_t* V = (const bf16_t*)p.V + ((int64_t)b * p.Lk + jrow) * p.ldv + h * D;
-  const bf16_t* Q = (const bf16_t*)p.Q + (int64_t)b * p.Lq * p.ldq + h * D;
-  const bf16_t* dO = (const bf16_t*)p.dO + (int64_t)b * p.Lq * p.ldo + h * D;
+  const Seq sq = seq_of(p, b);
+  const int Lq = sq.Lq, Lk = sq.Lk;
+  if ((int)blockIdx.x * 64 >= Lk) return;  // block-uniform
+  const int jrow = min(j, Lk - 1);
+  const bf16_t* K = (const bf16_t*)p.K + (sq.kbase + jrow) * p.ldk + h * D;
+  const bf16_t* V = (const bf16_t*)p.V + (sq.kbase + jrow) * p.ldv + h * D;
+  const bf16_t* Q = (const bf16_t*)p.Q + sq.qbase * p.ldq + h * D;
+  const bf16_t* dO = (const bf16_t*)p.dO + sq.qbase * p.ldo + h * D;
   bf16x8_t fk[D / 32], fv[D / 32];
 #pragma unroll
   for (int s = 0; s < D / 32; ++s) {
     fk[s] = ld_frag_global(K + 32 * s + 8 * g);
     fv[s] = ld_frag_global(V + 32 * s + 8 * g);
   }
-  const bool jmask = (j >= p.Lk) || (p.key_pad && p.key_pad[(int64_t)b * p.Lk + jrow]);
+  const bool jmask = (j >= Lk) || (p.key_pad && p.key_pad[(int64_t)b * p.Lk + jrow]);
 
   f32x4_t dk[D / 16], dv[D / 16];
 #pragma unroll
   for (int t = 0; t < D / 16; ++t) { dk[t] = f32x4_t{0.f, 0.f, 0.f, 0.f}; dv[t] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
 
-  for (int i0 = 0; i0 < p.Lq; i0 += OT) {
+  for (int i0 = 0; i0 < Lq; i0 += OT) {
     __syncthreads();
-    stage_tile<D>(Qs, Q, p.ldq, i0, p.Lq);
-    stage_tile<D>(dOs, dO, p.ldo, i0, p.Lq);
+    stage_tile<D>(Qs, Q, p.ldq, i0, Lq);
+    stage_tile<D>(dOs, dO, p.ldo, i0, Lq);
     if (threadIdx.x < OT) {
-      const int i = min(i0 + (int)threadIdx.x, p.Lq - 1);
+      const int i = min(i0 + (int)threadIdx.x, Lq - 1);
       const int64_t si = ((int64_t)b * p.H + h) * p.Lq + i;
       s_lse[threadIdx.x] = p.LSE[si];
       s_dl[threadIdx.x] = p.delta[si];
@@ -304,7 +313,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(AttnParams p) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int il = 16 * qt + 4 * g + r, i = i0 + il;
-        const bool msk = jmask || i >= p.Lq || (p.causal && j > i);
+        const bool msk = jmask || i >= Lq || (p.causal && j > i);
         float pr = msk ? 0.f : __expf(sc[r] * p.scale - s_lse[il]);
         float dpv = dp[r], pdv = pr;
         if (p.drop_thr) {
@@ -326,9 +335,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(AttnParams p) {
       dk[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x_cols<D>(Qs, 16 * t, 1, lane), ys1, dk[t], 0, 0, 0);
     }
   }
-  if (j < p.Lk) {
-    bf16_t* oK = (bf16_t*)p.dK + ((int64_t)b * p.Lk + j) * p.lddk + h * D;
-    bf16_t* oV = (bf16_t*)p.dV + ((int64_t)b * p.Lk + j) * p.lddv + h * D;
+  if (j < Lk) {
+    bf16_t* oK = (bf16_t*)p.dK + (sq.kbase + j) * p.lddk + h * D;
+    bf16_t* oV = (bf16_t*)p.dV + (sq.kbase + j) * p.lddv + h * D;
 #pragma unroll
     for (int t = 0; t < D / 16; ++t) {
       uint2 wk, wv;

@@ -53,6 +53,7 @@ class TransformerModel(NMTModel):
     def __init__(self, opt):
         super().__init__(opt)
         self.save_trip = False
+        self.packed = True  # skip padding rows while training (collate_fn's batches are right-padded)
         self.reducer = None
         self.model = None
 
@@ -169,11 +170,18 @@ class TransformerModel(NMTModel):
             if idle:
                 shard = tuple(x[:1] for x in batch)
             src_seq, src_pos, tgt_seq, tgt_pos = (x.to(self.device, non_blocking=True) for x in shard)
-            gold = tgt_seq[:, 1:]
             if not validation:
                 self.reducer.zero_grad() if self.reducer else self.optimiser.zero_grad()
-            pred = m(src_seq, src_pos, tgt_seq, tgt_pos)
-            loss, stats = ops.xent(pred.view(-1, pred.size(2)), gold, o.label_smoothing, unit_grad=not idle)
+            pred = None
+            if self.packed and not (validation and o.log):
+                try:  # the network on the batch without its padding rows: same loss, counts and gradients
+                    pred, gold = m.forward_packed(src_seq, src_pos, tgt_seq, tgt_pos)
+                except ValueError:  # not a right-padded batch
+                    self.packed = False
+            if pred is None:
+                pred = m(src_seq, src_pos, tgt_seq, tgt_pos)
+                gold = tgt_seq[:, 1:]
+            loss, stats = ops.xent(pred.view(-1, pred.size(-1)), gold, o.label_smoothing, unit_grad=not idle)
             if idle:
                 loss, stats = loss * 0.0, stats * 0.0
             if not validation:

@@ -29,9 +29,9 @@ class EncoderLayer(nn.Module):
         self.slf_attn = MultiHeadAttention(n_head, d_model, d_k, d_v, dropout=dropout)
         self.pos_ffn = PositionwiseFeedForward(d_model, d_inner, dropout=dropout)
 
-    def forward_2d(self, x, B, L, key_pad=None, dense_mask=None, row_pad=None, want_attn=False):
+    def forward_2d(self, x, B, L, key_pad=None, dense_mask=None, row_pad=None, want_attn=False, off=None):
         x, attn = self.slf_attn.forward_2d(x, x, B, L, L, key_pad=key_pad, dense_mask=dense_mask, row_pad=row_pad,
-                                           want_attn=want_attn, self_attn=True)
+                                           want_attn=want_attn, self_attn=True, q_off=off, k_off=off)
         x = self.pos_ffn.forward_2d(x, row_pad=row_pad)
         return x, attn
 
@@ -53,11 +53,12 @@ class DecoderLayer(nn.Module):
         self.pos_ffn = PositionwiseFeedForward(d_model, d_inner, dropout=dropout)
 
     def forward_2d(self, x, enc, B, Lt, Ls, key_pad=None, src_key_pad=None, causal=True, slf_dense=None,
-                   cross_dense=None, row_pad=None, want_attn=False):
+                   cross_dense=None, row_pad=None, want_attn=False, off=None, src_off=None):
         x, a1 = self.slf_attn.forward_2d(x, x, B, Lt, Lt, key_pad=key_pad, causal=causal, dense_mask=slf_dense,
-                                         row_pad=row_pad, want_attn=want_attn, self_attn=True)
+                                         row_pad=row_pad, want_attn=want_attn, self_attn=True, q_off=off, k_off=off)
         x, a2 = self.enc_attn.forward_2d(x, enc, B, Lt, Ls, key_pad=src_key_pad, dense_mask=cross_dense,
-                                         row_pad=row_pad, want_attn=want_attn, self_attn=False)
+                                         row_pad=row_pad, want_attn=want_attn, self_attn=False, q_off=off,
+                                         k_off=src_off)
         x = self.pos_ffn.forward_2d(x, row_pad=row_pad)
         return x, a1, a2
 

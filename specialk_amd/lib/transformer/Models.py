@@ -57,6 +57,52 @@ def _check_ids(seq, pos, n_vocab, n_pos):
         raise IndexError(f"position {int(pos.max())} outside the position table of {n_pos} rows")
 
 
+class PackPlan:
+    """Row bookkeeping of a right-padded (B, L) id batch stored without its padding: sentence b
+    owns rows off[b] .. off[b+1]-1 of every packed activation; idx[r] is the flat position
+    b*L + i of packed row r inside the padded batch."""
+
+    def __init__(self, lens, L, max_len):
+        B = lens.shape[0]
+        ends = torch.cumsum(lens, 0)
+        n = self.n = int(max_len[1])
+        self.B, self.L, self.max_len = B, L, int(max_len[0])
+        self.off = torch.zeros(B + 1, dtype=torch.int32, device=lens.device)
+        self.off[1:] = ends
+        r = torch.arange(n, device=lens.device)
+        b = torch.searchsorted(ends, r, right=True)
+        self.idx = b * L + (r - (ends - lens)[b])
+
+
+def plan_packing(seqs, trims, check=None):
+    """PackPlans for right-padded id batches `seqs` (each (B, L) on the GPU), keeping the first
+    len_b - trim tokens of every sentence.  One device -> host copy fetches what the host must
+    know (row counts, longest sentence, whether the batches really are right-padded and, if
+    `check` is given, whether ids / positions fit their tables)."""
+    lens, facts = [], []
+    for seq, trim in zip(seqs, trims):
+        nz = seq.ne(Constants.PAD)
+        ln = nz.sum(1)
+        ar = torch.arange(seq.shape[1], device=seq.device)
+        facts += [(nz == (ar[None, :] < ln[:, None])).all().to(torch.int64), (ln - trim).min()]
+        ln = (ln - trim).clamp_min(0)
+        lens.append(ln)
+        facts += [ln.max(), ln.sum()]
+    if check is not None:
+        for t, limit in check:
+            facts += [(t.max() < limit).to(torch.int64) * (t.min() >= 0).to(torch.int64)]
+    facts = torch.stack(facts).cpu().tolist()
+    plans = []
+    for k, (seq, ln) in enumerate(zip(seqs, lens)):
+        ok, lo, mx, n = facts[4 * k:4 * k + 4]
+        if not ok or lo < 0:
+            raise ValueError("packed execution needs right-padded batches whose sentences hold at least `trim` tokens")
+        plans.append(PackPlan(ln, seq.shape[1], (mx, n)))
+    if check is not None and not all(facts[4 * len(seqs):]):
+        raise IndexError("token id or position outside its embedding table")
+    return plans
+
+
 class Encoder(nn.Module):
     """A encoder model with self attention mechanism (lib/transformer/Models.py:72-129)."""
 
@@ -88,6 +134,16 @@ class Encoder(nn.Module):
         if return_attns:
             return enc_output, attns
         return (enc_output,)
+
+
+    def forward_packed(self, src_seq, src_pos, plan):
+        """Encoder over the packed rows of `plan` (no padding rows anywhere): -> (n_src_tokens, d)."""
+        flat = plan.idx
+        x = ops.EmbedFn.apply(src_seq.reshape(-1)[flat], src_pos.reshape(-1)[flat], self.src_word_emb.weight,
+                              self.position_enc.weight, self.compute_dtype)
+        for layer in self.layer_stack:
+            x, _ = layer.forward_2d(x, plan.B, plan.max_len, off=plan.off)
+        return x
 
 
 class Decoder(nn.Module):
@@ -128,6 +184,17 @@ class Decoder(nn.Module):
         if return_attns:
             return dec_output, slf_attns, enc_attns
         return (dec_output,)
+
+
+    def forward_packed(self, tgt_seq, tgt_pos, plan, enc_packed, src_plan):
+        """Decoder over packed target rows attending to packed encoder rows: -> (n_tgt_tokens, d)."""
+        flat = plan.idx
+        x = ops.EmbedFn.apply(tgt_seq.reshape(-1)[flat], tgt_pos.reshape(-1)[flat], self.tgt_word_emb.weight,
+                              self.position_enc.weight, self.compute_dtype)
+        for layer in self.layer_stack:
+            x, _, _ = layer.forward_2d(x, enc_packed, plan.B, plan.max_len, src_plan.max_len, causal=True,
+                                       off=plan.off, src_off=src_plan.off)
+        return x
 
 
 class Transformer(nn.Module):
@@ -181,3 +248,24 @@ class Transformer(nn.Module):
         B, Lt, d = dec_output.shape
         seq_logit = self.project(dec_output.reshape(B * Lt, d))
         return seq_logit.view(B, Lt, -1)
+
+    def forward_packed(self, src_seq, src_pos, tgt_seq, tgt_pos):
+        """Training-time fast path: the same network on the batch WITHOUT its padding.
+
+        Returns (logits (n, V), gold (n,)) for the n non-pad target positions, sentence after sentence —
+        the rows of `forward(...)`'s result whose gold token is not PAD, in the same order, so
+        the summed loss, the accuracy count and every parameter gradient equal the padded path's.
+        Each sentence's last target token is never an input (forward drops it for the longest
+        sentence; for shorter ones its row predicts PAD, is ignored by the loss and — the decoder
+        being causal — seen by no other row), so packed target rows are tokens 0 .. len-2.
+        Requires right-padded batches (what collate_fn builds); raises ValueError otherwise."""
+        check = None
+        if self.encoder.check_ids:
+            enc, dec = self.encoder, self.decoder
+            check = [(src_seq, enc.src_word_emb.num_embeddings), (src_pos, enc.position_enc.num_embeddings),
+                     (tgt_seq, dec.tgt_word_emb.num_embeddings), (tgt_pos, dec.position_enc.num_embeddings)]
+        src_plan, tgt_plan = plan_packing([src_seq, tgt_seq], [0, 1], check)
+        enc_packed = self.encoder.forward_packed(src_seq, src_pos, src_plan)
+        dec_packed = self.decoder.forward_packed(tgt_seq, tgt_pos, tgt_plan, enc_packed, src_plan)
+        gold = tgt_seq.reshape(-1)[tgt_plan.idx + 1]
+        return self.project(dec_packed), gold

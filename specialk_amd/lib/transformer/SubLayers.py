@@ -34,10 +34,12 @@ class MultiHeadAttention(nn.Module):
 
     # -- fast path used by the encoder / decoder stacks
     def forward_2d(self, q_in, kv_in, B, Lq, Lk, key_pad=None, causal=False, dense_mask=None, row_pad=None,
-                   want_attn=False, self_attn=None):
-        """q_in (B*Lq, d), kv_in (B*Lk, d) -> (LayerNorm(fc(attn) + q_in) with pad rows zeroed, attn|None)."""
+                   want_attn=False, self_attn=None, q_off=None, k_off=None):
+        """q_in (B*Lq, d), kv_in (B*Lk, d) -> (LayerNorm(fc(attn) + q_in) with pad rows zeroed, attn|None).
+        With q_off / k_off (int32 [B+1] row offsets) the inputs are packed token rows and Lq / Lk the
+        longest sequences."""
         training = self.training
-        cfg = dict(B=B, Lq=Lq, Lk=Lk, H=self.n_head, dk=self.d_k, dv=self.d_v,
+        cfg = dict(B=B, Lq=Lq, Lk=Lk, H=self.n_head, dk=self.d_k, dv=self.d_v, q_off=q_off, k_off=k_off,
                    self_attn=(q_in is kv_in) if self_attn is None else self_attn,
                    key_pad=key_pad, causal=bool(causal), dense_mask=dense_mask,
                    scale=1.0 / float(self.attention.temperature),

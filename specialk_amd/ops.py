@@ -148,7 +148,8 @@ class MHAFn(torch.autograd.Function):
     """Projections + scaled-dot-product attention + output projection
     (lib/transformer/SubLayers.py:46-62 without the LayerNorm, lib/transformer/Modules.py:17-28).
 
-    q_in (B*Lq, d), kv_in (B*Lk, d).  Q/K/V projections land in column slices of one buffer and
+    q_in (B*Lq, d), kv_in (B*Lk, d) — or, with cfg["q_off"] / cfg["k_off"] (int32 row offsets per
+    sentence), packed token rows without padding.  Q/K/V projections land in column slices of one buffer and
     the attention kernel reads heads in place (no permute/contiguous copies); masks come from
     key_pad (B,Lk) uint8 / causal / an optional dense (B,Lq,Lk) uint8 mask.
     Returns (fc_out (B*Lq, d), attn (h*B, Lq, Lk) or None)."""
@@ -158,7 +159,7 @@ class MHAFn(torch.autograd.Function):
         B, Lq, Lk, H, dk, dv = cfg["B"], cfg["Lq"], cfg["Lk"], cfg["H"], cfg["dk"], cfg["dv"]
         dt, dev = q_in.dtype, q_in.device
         d = q_in.shape[1]
-        Tq, Tk = B * Lq, B * Lk
+        Tq, Tk = q_in.shape[0], kv_in.shape[0]  # B*Lq, B*Lk padded; token counts when packed
         self_attn = cfg["self_attn"]
         Wqc, Wkc, Wvc, Woc = (compute_weight(w, dt) for w in (Wq, Wk, Wv, Wo))
         nq, nk, nv = H * dk, H * dk, H * dv
@@ -180,7 +181,8 @@ class MHAFn(torch.autograd.Function):
         P = torch.empty((H * B, Lq, Lk), dtype=dt, device=dev) if cfg["want_attn"] else None
         seed = next_seed() if cfg["p_attn"] > 0 else 0
         L.attn_fwd(Q, K, V, O, lse, B, H, Lq, Lk, dk, dv, ldq, ldk, ldv, nv, cfg["scale"], key_pad=cfg["key_pad"],
-                   dense_mask=cfg["dense_mask"], causal=cfg["causal"], p_drop=cfg["p_attn"], seed=seed, P_out=P)
+                   dense_mask=cfg["dense_mask"], causal=cfg["causal"], p_drop=cfg["p_attn"], seed=seed, P_out=P,
+                   q_off=cfg.get("q_off"), k_off=cfg.get("k_off"))
         out = L.gemm(L.GEMM_NT, O, Woc, Tq, d, nv, nv, nv, bias=bo.detach())
         ctx.save_for_backward(q_in, kv_in, Q, K, V, O, lse, Wq, Wk, Wv, Wo)
         ctx.cfg, ctx.seed, ctx.lds = cfg, seed, (ldq, ldk, ldv)
@@ -195,7 +197,7 @@ class MHAFn(torch.autograd.Function):
         B, Lq, Lk, H, dk, dv = cfg["B"], cfg["Lq"], cfg["Lk"], cfg["H"], cfg["dk"], cfg["dv"]
         dt, dev = q_in.dtype, q_in.device
         d = q_in.shape[1]
-        Tq, Tk = B * Lq, B * Lk
+        Tq, Tk = q_in.shape[0], kv_in.shape[0]
         nq, nk, nv = H * dk, H * dk, H * dv
         ldq, ldk, ldv = ctx.lds
         dout = dout.contiguous()
@@ -218,7 +220,7 @@ class MHAFn(torch.autograd.Function):
         delta = torch.empty((B, H, Lq), dtype=f32, device=dev)
         L.attn_bwd(Q, K, V, O, dO, lse, dQ, dK, dV, delta, B, H, Lq, Lk, dk, dv, ldq, ldk, ldv, nv, lddq, lddk, lddv,
                    cfg["scale"], key_pad=cfg["key_pad"], dense_mask=cfg["dense_mask"], causal=cfg["causal"],
-                   p_drop=cfg["p_attn"], seed=ctx.seed)
+                   p_drop=cfg["p_attn"], seed=ctx.seed, q_off=cfg.get("q_off"), k_off=cfg.get("k_off"))
         # projections
         dWq = L.gemm(L.GEMM_TN, dQ, q_in, nq, d, Tq, lddq, q_in.stride(0), out_dtype=f32)
         dWk = L.gemm(L.GEMM_TN, dK, kv_in, nk, d, Tk, lddk, kv_in.stride(0), out_dtype=f32)
