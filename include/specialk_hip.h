@@ -189,6 +189,16 @@ int skhip_adam_multi(const uint64_t* param_ptrs, const uint64_t* grad_ptrs, cons
 /* dst = (bf16) src for n tensors (same table convention), used once after loading weights. */
 int skhip_cast_multi(const uint64_t* src_f32_ptrs, const uint64_t* dst_bf16_ptrs,
                      const int64_t* counts, int n, int64_t max_count, void* stream);
+
+/* Derived working copies of weight matrices, refreshed in one launch after the optimiser step:
+ * entry t reads the fp32 matrix src[t] ([R][C], contiguous) and writes it, cast to bf16 (or kept
+ * fp32), into dst[t] with row stride ld either as it is or transposed.  meta holds four int64 per
+ * entry: R, C, ld, flags (bit 0: transpose, bit 1: fp32 destination).  Used to keep [Wq;Wk;Wv]
+ * row-concatenations (one fused projection GEMM instead of SubLayers.py:46-48's three) and W^T
+ * copies (input-gradient GEMMs with a K-contiguous weight operand).  max_tiles = the largest
+ * ceil(R/32)*ceil(C/32) over the entries.                                                  */
+int skhip_cast2d_multi(const uint64_t* src_f32_ptrs, const uint64_t* dst_ptrs, const int64_t* meta,
+                       int n, int64_t max_tiles, void* stream);
 /* dst[i] = convert(src[i]); dtypes SK_F32 / SK_BF16.                                      */
 int skhip_convert(const void* src, void* dst, int64_t n, int src_dtype, int dst_dtype, void* stream);
 

@@ -21,7 +21,7 @@ LIB_PATH = os.path.join(_HERE, "libspecialk_hip.so")
 EXPORTS = [
     "skhip_version", "skhip_last_error", "skhip_init", "skhip_gemm", "skhip_colsum", "skhip_attn_fwd",
     "skhip_attn_bwd", "skhip_attn_varlen_fwd", "skhip_attn_varlen_bwd", "skhip_add_ln_fwd", "skhip_add_ln_bwd_ws_floats", "skhip_add_ln_bwd", "skhip_embed_fwd",
-    "skhip_embed_bwd", "skhip_xent_fwd_bwd", "skhip_adam_multi", "skhip_cast_multi", "skhip_convert",
+    "skhip_embed_bwd", "skhip_xent_fwd_bwd", "skhip_adam_multi", "skhip_cast_multi", "skhip_cast2d_multi", "skhip_convert",
     "skhip_decode_attn", "skhip_beam_topk_ws_bytes", "skhip_beam_topk", "skhip_gather_rows",
 ]
 
@@ -60,6 +60,7 @@ def load():
     lib.skhip_xent_fwd_bwd.argtypes = [c_p] * 4 + [c_i64, c_i64, c_i64, c_f32, c_f32, c_i64, c_f32, c_int, c_p]
     lib.skhip_adam_multi.argtypes = [c_p] * 6 + [c_int, c_i64, c_f32, c_f32, c_f32, c_f32, c_int, c_f32, c_p]
     lib.skhip_cast_multi.argtypes = [c_p] * 3 + [c_int, c_i64, c_p]
+    lib.skhip_cast2d_multi.argtypes = [c_p] * 3 + [c_int, c_i64, c_p]
     lib.skhip_convert.argtypes = [c_p, c_p, c_i64, c_int, c_int, c_p]
     lib.skhip_decode_attn.argtypes = [c_p] * 6 + [c_int] * 6 + [c_i64, c_i64, c_f32, c_int, c_int, c_p]
     lib.skhip_beam_topk.argtypes = [c_p] * 6 + [c_int, c_int, c_i64, c_int, c_int, c_p]
@@ -257,6 +258,12 @@ def cast_multi(src_table, dst_table, counts, n, max_count):
     lib = load()
     _check(lib.skhip_cast_multi(_ptr(src_table), _ptr(dst_table), _ptr(counts), n, max_count, _stream()),
            "skhip_cast_multi")
+
+
+def cast2d_multi(src_table, dst_table, meta, n, max_tiles):
+    """Tables are int64 device tensors: source / destination pointers (n,), meta (n, 4) = R, C, ld, flags."""
+    _check(load().skhip_cast2d_multi(_ptr(src_table), _ptr(dst_table), _ptr(meta), n, max_tiles, _stream()),
+           "skhip_cast2d_multi")
 
 
 def convert(src, dst):

@@ -63,6 +63,40 @@ __global__ __launch_bounds__(256) void cast_multi_kernel(const uint64_t* __restr
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) d[i] = f32_to_bf16(s[i]);
 }
 
+// Entry t: fp32 matrix src [R][C] (contiguous) -> dst, row stride ld, as bf16 or fp32, either as it
+// is (dst[r][c]) or transposed (dst[c][r]).  32x32 tiles through LDS so both sides stay coalesced.
+__global__ __launch_bounds__(256) void cast2d_multi_kernel(const uint64_t* __restrict__ sp, const uint64_t* __restrict__ dp,
+                                                           const int64_t* __restrict__ meta) {
+  __shared__ float tile[32][33];
+  const int t = blockIdx.y;
+  const int64_t R = meta[4 * t], C = meta[4 * t + 1], ld = meta[4 * t + 2], flags = meta[4 * t + 3];
+  const bool transpose = flags & 1, dst_f32 = flags & 2;
+  const float* s = (const float*)sp[t];
+  const int64_t tr = (R + 31) / 32, tc = (C + 31) / 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int64_t id = blockIdx.x; id < tr * tc; id += gridDim.x) {  // block-uniform trip count
+    const int64_t r0 = (id / tc) * 32, c0 = (id % tc) * 32;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int64_t r = r0 + ty + 8 * i, c = c0 + tx;
+      tile[ty + 8 * i][tx] = (r < R && c < C) ? s[r * C + c] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      // transposed: this thread writes dst[c0 + ty + 8i][r0 + tx]; plain: dst[r0 + ty + 8i][c0 + tx]
+      const int64_t orow = (transpose ? c0 : r0) + ty + 8 * i, ocol = (transpose ? r0 : c0) + tx;
+      const int64_t nrow = transpose ? C : R, ncol = transpose ? R : C;
+      if (orow < nrow && ocol < ncol) {
+        const float v = transpose ? tile[tx][ty + 8 * i] : tile[ty + 8 * i][tx];
+        if (dst_f32) ((float*)dp[t])[orow * ld + ocol] = v;
+        else ((bf16_t*)dp[t])[orow * ld + ocol] = f32_to_bf16(v);
+      }
+    }
+    __syncthreads();
+  }
+}
+
 template <typename TS, typename TD>
 __global__ __launch_bounds__(256) void convert_kernel(const TS* __restrict__ s, TD* __restrict__ d, int64_t n) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
@@ -108,6 +142,18 @@ extern "C" int skhip_cast_multi(const uint64_t* src_f32_ptrs, const uint64_t* ds
   dim3 grid(blocks_for(max_count, 4), (unsigned)n);
   hipLaunchKernelGGL(cast_multi_kernel, grid, dim3(256), 0, stream, src_f32_ptrs, dst_bf16_ptrs, counts);
   SK_CHECK_LAUNCH("skhip_cast_multi");
+  return SK_OK;
+}
+
+extern "C" int skhip_cast2d_multi(const uint64_t* src_f32_ptrs, const uint64_t* dst_ptrs, const int64_t* meta, int n,
+                                  int64_t max_tiles, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SK_CHECK_ARG(n >= 0 && n <= 65535, "skhip_cast2d_multi: n=%d", n);
+  if (n == 0) return SK_OK;
+  SK_CHECK_ARG(src_f32_ptrs && dst_ptrs && meta, "skhip_cast2d_multi: null table");
+  int64_t bx = max_tiles < 1 ? 1 : (max_tiles > 512 ? 512 : max_tiles);
+  hipLaunchKernelGGL(cast2d_multi_kernel, dim3((unsigned)bx, (unsigned)n), dim3(256), 0, stream, src_f32_ptrs, dst_ptrs, meta);
+  SK_CHECK_LAUNCH("skhip_cast2d_multi");
   return SK_OK;
 }
 

@@ -64,6 +64,101 @@ def registered_copy(p):
     return c.tensor if c is not None and c.ref() is p else None
 
 
+# ----------------------------------------------------------------------------- derived copies
+class _Derived:
+    __slots__ = ("refs", "versions", "ptrs", "tensor", "rows")
+
+
+_derived = {}
+_derived_tables = None  # device tables of every registered derived copy, for the post-step refresh
+
+
+def _as2d(p):
+    return p.shape[0], p.numel() // p.shape[0]
+
+
+def derived_weight(kind, params):
+    """Working copies derived from fp32 master parameters, kept current by `refresh_derived`
+    (one launch after the optimiser step) and rebuilt lazily when a parameter was modified
+    through torch:
+      "cat"  : bf16 [sum R_i][C]   the matrices stacked by rows (one fused projection GEMM),
+      "catT" : bf16 [C][sum R_i]   their transposes side by side (K-contiguous weight operand of
+                                   the input-gradient GEMMs),
+      "bias" : fp32 [sum n_i]      bias vectors concatenated."""
+    global _derived_tables
+    key = (kind,) + tuple(id(p) for p in params)
+    d = _derived.get(key)
+    fresh = d is not None and all(r() is p and v == p._version and q == p.data_ptr()
+                                  for r, v, q, p in zip(d.refs, d.versions, d.ptrs, params))
+    if fresh:
+        return d.tensor
+    dev = params[0].device
+    if kind == "bias":
+        total = sum(p.numel() for p in params)
+        shape, dt = (total,), torch.float32
+    else:
+        C = _as2d(params[0])[1]
+        assert all(_as2d(p)[1] == C for p in params)
+        total = sum(_as2d(p)[0] for p in params)
+        shape, dt = ((total, C) if kind == "cat" else (C, total)), torch.bfloat16
+    if d is None or d.tensor.shape != shape or d.tensor.device != dev:
+        d = _Derived()
+        d.tensor = torch.empty(shape, dtype=dt, device=dev)
+        _derived[key] = d
+        _derived_tables = None
+    rows, off = [], 0
+    esz = d.tensor.element_size()
+    for p in params:
+        if kind == "bias":
+            rows.append((p.data_ptr(), d.tensor.data_ptr() + off * esz, 1, p.numel(), total, 2))
+            off += p.numel()
+        elif kind == "cat":
+            R, C = _as2d(p)
+            rows.append((p.data_ptr(), d.tensor.data_ptr() + off * C * esz, R, C, C, 0))
+            off += R
+        else:
+            R, C = _as2d(p)
+            rows.append((p.data_ptr(), d.tensor.data_ptr() + off * esz, R, C, total, 1))
+            off += R
+    d.rows = rows
+    d.refs = [weakref.ref(p) for p in params]
+    d.versions = [p._version for p in params]
+    d.ptrs = [p.data_ptr() for p in params]
+    if any(q != r[0] for q, r in zip(d.ptrs, rows)):
+        _derived_tables = None
+    _launch_cast2d(_tables_of(rows, dev))
+    _derived_tables = None  # pointers may have changed
+    return d.tensor
+
+
+def _tables_of(rows, dev):
+    t = torch.tensor(rows, dtype=torch.int64)
+    tiles = int((((t[:, 2] + 31) // 32) * ((t[:, 3] + 31) // 32)).max())
+    return (t[:, 0].contiguous().to(dev), t[:, 1].contiguous().to(dev), t[:, 2:].contiguous().to(dev), len(rows), tiles)
+
+
+def _launch_cast2d(tab):
+    L.cast2d_multi(tab[0], tab[1], tab[2], tab[3], tab[4])
+
+
+def refresh_derived():
+    """Rewrite every derived copy from the master parameters (called by the optimiser after its
+    update, whose kernel changes the parameters without touching torch's version counters)."""
+    global _derived_tables
+    if not _derived:
+        return
+    if _derived_tables is None:
+        dead = [k for k, d in _derived.items() if any(r() is None for r in d.refs)]
+        for k in dead:
+            del _derived[k]
+        by_dev = {}
+        for d in _derived.values():
+            by_dev.setdefault(d.tensor.device, []).extend(d.rows)
+        _derived_tables = [_tables_of(rows, dev) for dev, rows in by_dev.items()]
+    for tab in _derived_tables:
+        _launch_cast2d(tab)
+
+
 def _bias_grad(dy, T, N):
     """Column sums of dy, unless the LayerNorm backward that produced dy already attached them."""
     pre = getattr(dy, "_sk_colsum", None)
@@ -74,6 +169,43 @@ def _bias_grad(dy, T, N):
 
 def _w2d(w):
     return w.reshape(w.shape[0], -1)  # Conv1d(k=1) weights (out,in,1) are linear maps (out,in)
+
+
+def _input_grad(dy, ldy, Ws, T, d_in, dt, alpha=1.0, aux=None, epilogue=0):
+    """dx (T, d_in) = alpha * dy (T, sum n_i; row stride ldy) @ [W_1; W_2; ...] for weights W_i (n_i, d_in).
+    bf16: ONE GEMM against the K-contiguous transposed copy; fp32: one exact-fp32 GEMM per weight."""
+    n_tot = sum(_as2d(w)[0] for w in Ws)
+    if dt == torch.bfloat16:
+        return L.gemm(L.GEMM_NT, dy, derived_weight("catT", Ws), T, d_in, n_tot, ldy, n_tot, alpha=alpha, aux=aux,
+                      epilogue=epilogue)
+    assert len(Ws) == 1 or (aux is None and epilogue == 0)
+    dx, off = None, 0
+    for w in Ws:
+        n = _as2d(w)[0]
+        if dx is None:
+            dx = L.gemm(L.GEMM_NN, dy[:, off:off + n], _w2d(w.detach()), T, d_in, n, ldy, d_in, alpha=alpha, aux=aux,
+                        epilogue=epilogue)
+        else:
+            L.gemm(L.GEMM_NN, dy[:, off:off + n], _w2d(w.detach()), T, d_in, n, ldy, d_in, alpha=alpha, out=dx, ldc=d_in,
+                   epilogue=L.EPI_ACCUM)
+        off += n
+    return dx
+
+
+def _project(x, Ws, bs, out, ldc, dt):
+    """out[:, blocks] = x @ W_i^T + b_i for the stacked weights: one fused GEMM in bf16, one GEMM each in fp32."""
+    T, d = x.shape
+    n_tot = sum(_as2d(w)[0] for w in Ws)
+    if dt == torch.bfloat16:
+        W = derived_weight("cat", Ws) if len(Ws) > 1 else _w2d(compute_weight(Ws[0], dt))
+        b = derived_weight("bias", bs) if len(bs) > 1 else bs[0].detach()
+        L.gemm(L.GEMM_NT, x, W, T, n_tot, d, x.stride(0), d, out=out, ldc=ldc, bias=b)
+        return
+    off = 0
+    for w, b in zip(Ws, bs):
+        n = _as2d(w)[0]
+        L.gemm(L.GEMM_NT, x, _w2d(w.detach()), T, n, d, x.stride(0), d, out=out[:, off:off + n], ldc=ldc, bias=b.detach())
+        off += n
 
 
 # ----------------------------------------------------------------------------- linear
@@ -95,11 +227,10 @@ class LinearFn(torch.autograd.Function):
         x, W = ctx.saved_tensors
         dy = dy.contiguous()
         T, K = x.shape
-        Wc = _w2d(compute_weight(W, x.dtype))
-        N = Wc.shape[0]
+        N = _as2d(W)[0]
         dx = dW = db = None
         if ctx.needs_input_grad[0]:
-            dx = L.gemm(L.GEMM_NN, dy, Wc, T, K, N, N, K, alpha=ctx.alpha)
+            dx = _input_grad(dy, N, (W,), T, K, x.dtype, alpha=ctx.alpha)
         if ctx.needs_input_grad[1]:
             dW = L.gemm(L.GEMM_TN, dy, x, N, K, T, N, x.stride(0), alpha=ctx.alpha, out_dtype=torch.float32)
             dW = dW.view(W.shape)
@@ -132,12 +263,11 @@ class FFNFn(torch.autograd.Function):
         x, h, W1, W2 = ctx.saved_tensors
         dy = dy.contiguous()
         T, d = x.shape
-        W1c, W2c = _w2d(compute_weight(W1, x.dtype)), _w2d(compute_weight(W2, x.dtype))
-        F = W1c.shape[0]
-        dh = L.gemm(L.GEMM_NN, dy, W2c, T, F, d, d, F, aux=h, epilogue=L.EPI_RELU_MASK)
+        F = _as2d(W1)[0]
+        dh = _input_grad(dy, d, (W2,), T, F, x.dtype, aux=h, epilogue=L.EPI_RELU_MASK)
         dW2 = L.gemm(L.GEMM_TN, dy, h, d, F, T, d, F, out_dtype=torch.float32).view(W2.shape)
         db2 = _bias_grad(dy, T, d)
-        dx = L.gemm(L.GEMM_NN, dh, W1c, T, d, F, F, d)
+        dx = _input_grad(dh, F, (W1,), T, d, x.dtype)
         dW1 = L.gemm(L.GEMM_TN, dh, x, F, d, T, F, x.stride(0), out_dtype=torch.float32).view(W1.shape)
         db1 = L.colsum(dh, T, F, F)
         return dx, dW1, db1, dW2, db2
@@ -149,10 +279,11 @@ class MHAFn(torch.autograd.Function):
     (lib/transformer/SubLayers.py:46-62 without the LayerNorm, lib/transformer/Modules.py:17-28).
 
     q_in (B*Lq, d), kv_in (B*Lk, d) — or, with cfg["q_off"] / cfg["k_off"] (int32 row offsets per
-    sentence), packed token rows without padding.  Q/K/V projections land in column slices of one buffer and
-    the attention kernel reads heads in place (no permute/contiguous copies); masks come from
-    key_pad (B,Lk) uint8 / causal / an optional dense (B,Lq,Lk) uint8 mask.
-    Returns (fc_out (B*Lq, d), attn (h*B, Lq, Lk) or None)."""
+    sentence), packed token rows without padding.  Q/K/V projections land in column slices of one
+    buffer ([q|k|v] for self-attention, q and [k|v] otherwise; in bf16 each buffer is filled by ONE
+    GEMM against the stacked weights) and the attention kernel reads heads in place (no
+    permute/contiguous copies); masks come from key_pad (B,Lk) uint8 / causal / an optional dense
+    (B,Lq,Lk) uint8 mask.  Returns (fc_out (B*Lq, d), attn (h*B, Lq, Lk) or None)."""
 
     @staticmethod
     def forward(ctx, q_in, kv_in, Wq, bq, Wk, bk, Wv, bv, Wo, bo, cfg):
@@ -161,21 +292,19 @@ class MHAFn(torch.autograd.Function):
         d = q_in.shape[1]
         Tq, Tk = q_in.shape[0], kv_in.shape[0]  # B*Lq, B*Lk padded; token counts when packed
         self_attn = cfg["self_attn"]
-        Wqc, Wkc, Wvc, Woc = (compute_weight(w, dt) for w in (Wq, Wk, Wv, Wo))
         nq, nk, nv = H * dk, H * dk, H * dv
         if self_attn:
             qkv = torch.empty((Tq, nq + nk + nv), dtype=dt, device=dev)
-            ld = qkv.stride(0)
+            ldq = ldk = ldv = qkv.stride(0)
             Q, K, V = qkv[:, :nq], qkv[:, nq:nq + nk], qkv[:, nq + nk:]
-            ldq = ldk = ldv = ld
+            _project(q_in, (Wq, Wk, Wv), (bq, bk, bv), qkv, ldq, dt)
         else:
             Q = torch.empty((Tq, nq), dtype=dt, device=dev)
             kv = torch.empty((Tk, nk + nv), dtype=dt, device=dev)
             K, V = kv[:, :nk], kv[:, nk:]
             ldq, ldk, ldv = nq, nk + nv, nk + nv
-        L.gemm(L.GEMM_NT, q_in, Wqc, Tq, nq, d, q_in.stride(0), d, out=Q, ldc=ldq, bias=bq.detach())
-        L.gemm(L.GEMM_NT, kv_in, Wkc, Tk, nk, d, kv_in.stride(0), d, out=K, ldc=ldk, bias=bk.detach())
-        L.gemm(L.GEMM_NT, kv_in, Wvc, Tk, nv, d, kv_in.stride(0), d, out=V, ldc=ldv, bias=bv.detach())
+            _project(q_in, (Wq,), (bq,), Q, ldq, dt)
+            _project(kv_in, (Wk, Wv), (bk, bv), kv, ldk, dt)
         O = torch.empty((Tq, nv), dtype=dt, device=dev)
         lse = torch.empty((B, H, Lq), dtype=torch.float32, device=dev)
         P = torch.empty((H * B, Lq, Lk), dtype=dt, device=dev) if cfg["want_attn"] else None
@@ -183,7 +312,7 @@ class MHAFn(torch.autograd.Function):
         L.attn_fwd(Q, K, V, O, lse, B, H, Lq, Lk, dk, dv, ldq, ldk, ldv, nv, cfg["scale"], key_pad=cfg["key_pad"],
                    dense_mask=cfg["dense_mask"], causal=cfg["causal"], p_drop=cfg["p_attn"], seed=seed, P_out=P,
                    q_off=cfg.get("q_off"), k_off=cfg.get("k_off"))
-        out = L.gemm(L.GEMM_NT, O, Woc, Tq, d, nv, nv, nv, bias=bo.detach())
+        out = L.gemm(L.GEMM_NT, O, compute_weight(Wo, dt), Tq, d, nv, nv, nv, bias=bo.detach())
         ctx.save_for_backward(q_in, kv_in, Q, K, V, O, lse, Wq, Wk, Wv, Wo)
         ctx.cfg, ctx.seed, ctx.lds = cfg, seed, (ldq, ldk, ldv)
         if P is not None:
@@ -201,10 +330,9 @@ class MHAFn(torch.autograd.Function):
         nq, nk, nv = H * dk, H * dk, H * dv
         ldq, ldk, ldv = ctx.lds
         dout = dout.contiguous()
-        Wqc, Wkc, Wvc, Woc = (compute_weight(w, dt) for w in (Wq, Wk, Wv, Wo))
         f32 = torch.float32
         # output projection
-        dO = L.gemm(L.GEMM_NN, dout, Woc, Tq, nv, d, d, nv)
+        dO = _input_grad(dout, d, (Wo,), Tq, nv, dt)
         dWo = L.gemm(L.GEMM_TN, dout, O, d, nv, Tq, d, nv, out_dtype=f32)
         dbo = _bias_grad(dout, Tq, d)
         # attention core
@@ -221,19 +349,24 @@ class MHAFn(torch.autograd.Function):
         L.attn_bwd(Q, K, V, O, dO, lse, dQ, dK, dV, delta, B, H, Lq, Lk, dk, dv, ldq, ldk, ldv, nv, lddq, lddk, lddv,
                    cfg["scale"], key_pad=cfg["key_pad"], dense_mask=cfg["dense_mask"], causal=cfg["causal"],
                    p_drop=cfg["p_attn"], seed=ctx.seed, q_off=cfg.get("q_off"), k_off=cfg.get("k_off"))
-        # projections
-        dWq = L.gemm(L.GEMM_TN, dQ, q_in, nq, d, Tq, lddq, q_in.stride(0), out_dtype=f32)
-        dWk = L.gemm(L.GEMM_TN, dK, kv_in, nk, d, Tk, lddk, kv_in.stride(0), out_dtype=f32)
-        dWv = L.gemm(L.GEMM_TN, dV, kv_in, nv, d, Tk, lddv, kv_in.stride(0), out_dtype=f32)
-        dbq, dbk, dbv = L.colsum(dQ, Tq, nq, lddq), L.colsum(dK, Tk, nk, lddk), L.colsum(dV, Tk, nv, lddv)
-        dq_in = L.gemm(L.GEMM_NN, dQ, Wqc, Tq, d, nq, lddq, d)
+        # projections: weight gradients, bias gradients (column sums) and input gradients, each over the
+        # widest buffer that shares an input ([dq|dk|dv] for self-attention, [dk|dv] otherwise)
         if cfg["self_attn"]:
-            L.gemm(L.GEMM_NN, dK, Wkc, Tk, d, nk, lddk, d, out=dq_in, ldc=d, epilogue=L.EPI_ACCUM)
-            L.gemm(L.GEMM_NN, dV, Wvc, Tk, d, nv, lddv, d, out=dq_in, ldc=d, epilogue=L.EPI_ACCUM)
+            n3 = nq + nk + nv
+            dW = L.gemm(L.GEMM_TN, dqkv, q_in, n3, d, Tq, lddq, q_in.stride(0), out_dtype=f32)
+            db = L.colsum(dqkv, Tq, n3, lddq)
+            dWq, dWk, dWv = dW[:nq], dW[nq:nq + nk], dW[nq + nk:]
+            dbq, dbk, dbv = db[:nq], db[nq:nq + nk], db[nq + nk:]
+            dq_in = _input_grad(dqkv, lddq, (Wq, Wk, Wv), Tq, d, dt)
             dkv_in = None
         else:
-            dkv_in = L.gemm(L.GEMM_NN, dK, Wkc, Tk, d, nk, lddk, d)
-            L.gemm(L.GEMM_NN, dV, Wvc, Tk, d, nv, lddv, d, out=dkv_in, ldc=d, epilogue=L.EPI_ACCUM)
+            dWq = L.gemm(L.GEMM_TN, dQ, q_in, nq, d, Tq, lddq, q_in.stride(0), out_dtype=f32)
+            dbq = L.colsum(dQ, Tq, nq, lddq)
+            dW = L.gemm(L.GEMM_TN, dkv, kv_in, nk + nv, d, Tk, lddk, kv_in.stride(0), out_dtype=f32)
+            db = L.colsum(dkv, Tk, nk + nv, lddk)
+            dWk, dWv, dbk, dbv = dW[:nk], dW[nk:], db[:nk], db[nk:]
+            dq_in = _input_grad(dQ, lddq, (Wq,), Tq, d, dt)
+            dkv_in = _input_grad(dkv, lddk, (Wk, Wv), Tk, d, dt)
         return dq_in, dkv_in, dWq, dbq, dWk, dbk, dWv, dbv, dWo, dbo, None
 
 

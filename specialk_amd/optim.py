@@ -61,6 +61,7 @@ class FusedAdam(torch.optim.Optimizer):
             tables, n = self._tables(plist)
             b1, b2 = group["betas"]
             L.adam_multi(tables, n, max(p.numel() for p in plist), group["lr"], b1, b2, group["eps"], step)
+            ops.refresh_derived()  # stacked / transposed working copies follow the new weights
             for p in plist:
                 self.state[p]["step"] = step
         return loss

@@ -476,3 +476,32 @@ def test_add_ln_bwd_dx_colsum(L):
         _, mean, rstd = L.add_ln_fwd(x, res, gamma, beta, None, 1e-5, p, 7)
         dx, dres, dg, db, dxs = L.add_ln_bwd(dy, x, res, gamma, None, mean, rstd, p, 7, want_dx_colsum=True)
         assert rel_err(dxs, dx.double().sum(0)) <= (1e-5 if dtype == torch.float32 else 5e-3)
+
+
+def test_cast2d_multi_and_derived_weights(L):
+    """Stacked / transposed bf16 working copies and their refresh after an in-place update."""
+    from specialk_amd import ops
+    g = torch.Generator().manual_seed(21)
+    Ws = [torch.nn.Parameter(torch.randn(r, 40, generator=g).to(DEV)) for r in (24, 8, 33)]
+    conv = torch.nn.Parameter(torch.randn(50, 40, 1, generator=g).to(DEV))  # Conv1d(k=1) weight
+    bs = [torch.nn.Parameter(torch.randn(r, generator=g).to(DEV)) for r in (24, 8, 33)]
+
+    def check():
+        cat = ops.derived_weight("cat", tuple(Ws))
+        catT = ops.derived_weight("catT", tuple(Ws))
+        cT = ops.derived_weight("catT", (conv,))
+        bias = ops.derived_weight("bias", tuple(bs))
+        ref = torch.cat([w.detach() for w in Ws], 0)
+        assert cat.dtype == torch.bfloat16 and torch.equal(cat, ref.to(torch.bfloat16))
+        assert catT.shape == (40, 65) and torch.equal(catT, ref.t().to(torch.bfloat16))
+        assert torch.equal(cT, conv.detach().view(50, 40).t().to(torch.bfloat16))
+        assert bias.dtype == torch.float32 and torch.equal(bias, torch.cat([b.detach() for b in bs]))
+        return cat
+
+    first = check()
+    with torch.no_grad():
+        Ws[1].add_(1.0)            # torch-side change: version counter moves, copy is rebuilt on access
+    assert check().data_ptr() == first.data_ptr()
+    Ws[2].data.view(-1)[:5] = 7.0   # .data write: invisible to the version counter, like the Adam kernel
+    ops.refresh_derived()
+    check()
