@@ -50,6 +50,7 @@ struct GemmParams {
   int epi;
   int vec_c;  // C (and aux) allow 16-byte vector access
   float alpha;
+  int group;  // tile rows per rasterisation group (see tile_of)
 };
 
 constexpr int BM = 128, BN = 128;
@@ -60,6 +61,23 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, local = bid >> 3;
   int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
   return base + local;
+}
+
+// Block -> output tile.  Blocks that share an XCD get a contiguous run of tile numbers
+// (xcd_remap); inside a run the tiles walk down `group` tile rows before moving to the next tile
+// column, so the blocks resident on one XCD at a time cover a group x (resident/group) patch of
+// the output and re-use each other's A and B panels in that XCD's L2 instead of streaming a
+// whole operand through it.
+__device__ __forceinline__ void tile_of(const GemmParams& p, int bid, int& tile_m, int& tile_n) {
+  const int pid = xcd_remap(bid, p.tiles_m * p.tiles_n);
+  const int g = p.group;
+  if (g <= 1) { tile_n = pid % p.tiles_n; tile_m = pid / p.tiles_n; return; }
+  const int per_group = g * p.tiles_n;
+  const int first_m = (pid / per_group) * g;
+  const int rows = min(g, p.tiles_m - first_m);
+  const int in_group = pid % per_group;
+  tile_m = first_m + in_group % rows;
+  tile_n = in_group / rows;
 }
 
 // ---------------------------------------------------------------------------- epilogue
@@ -292,8 +310,8 @@ template <bool A_T, bool B_T, typename TOut, bool FAST>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wgid = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
-  const int tile_n = wgid % p.tiles_n, tile_m = wgid / p.tiles_n;
+  int tile_m, tile_n;
+  tile_of(p, blockIdx.x, tile_m, tile_n);
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int wrow = (wave >> 1) * 64, wcol = (wave & 1) * 64;
 
@@ -451,8 +469,8 @@ __global__ __launch_bounds__(256, 3) void gemm_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wgid = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
-  const int tile_n = wgid % p.tiles_n, tile_m = wgid / p.tiles_n;
+  int tile_m, tile_n;
+  tile_of(p, blockIdx.x, tile_m, tile_n);
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int wrow = (wave >> 1) * 64, wcol = (wave & 1) * 64;
 
@@ -546,8 +564,8 @@ __global__ __launch_bounds__(512, 1) void gemm_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wgid = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
-  const int tile_n = wgid % p.tiles_n, tile_m = wgid / p.tiles_n;
+  int tile_m, tile_n;
+  tile_of(p, blockIdx.x, tile_m, tile_n);
   const int m0 = tile_m * XM, n0 = tile_n * XN;
   const int wrow = (wave >> 2) * 128, wcol = (wave & 3) * 64;
 
@@ -697,8 +715,8 @@ template <bool A_T, bool B_T, bool FAST>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wgid = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
-  const int tile_n = wgid % p.tiles_n, tile_m = wgid / p.tiles_n;
+  int tile_m, tile_n;
+  tile_of(p, blockIdx.x, tile_m, tile_n);
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int wrow = (wave >> 1) * 64, wcol = (wave & 1) * 64;
 
@@ -881,6 +899,11 @@ extern "C" int skhip_gemm(int layout, const void* A, const void* B, void* C, con
   p.tiles_n = (int)((N + BN - 1) / BN);
   p.epi = epilogue;
   p.alpha = alpha;
+  // Grouped rasterisation pays when both operands are long panels that do not fit the L2s
+  // (measured on 8192^3: 870 -> 1317 TFLOP/s with the 256-tile kernel); with a short K the
+  // row-major order is better (its concurrent tiles write adjacent pieces of the same C rows).
+  p.group = (K >= 4096 && N >= 2048 && M >= 2048) ? 8 : 1;
+  { const char* e = getenv("SKHIP_GEMM_GROUP"); if (e) p.group = atoi(e); }
   const int esz = in_dtype == SK_BF16 ? 2 : 4;
   const int vecn = 16 / esz;
   const int osz = out_dtype == SK_BF16 ? 2 : 4;
@@ -899,11 +922,20 @@ extern "C" int skhip_gemm(int layout, const void* A, const void* B, void* C, con
   const char* env_staged = getenv("SKHIP_GEMM_STAGED");
   bool use_staged = layout == SK_GEMM_TN || (layout == SK_GEMM_NN && K >= 8192);
   if (env_staged && (env_staged[0] == '0' || env_staged[0] == '1')) use_staged = env_staged[0] == '1';
-  // 256x256-tile kernel: K-contiguous operands (NT) with many more 256-tiles than CUs.
+  // 256x256-tile kernel: K-contiguous operands (NT).  One block per CU, so what decides is how
+  // well the 256-tiles fill whole rounds of the chip (measured, 256 CUs, M = 25k..33k rows):
+  // it wins with many more tiles than CUs (generator: 835 vs 670 TFLOP/s), with a long K when the
+  // last round is mostly full (N = 512, K = 2048: 1000 vs 695; K = 35000: 711 vs 408), and for a
+  // short K only when everything fits a single round (200 tiles: 580 vs 479; 260 tiles: 460 vs 584).
   // SKHIP_GEMM_BIG=0/1 forces the choice (1 still requires NT + aligned operands).
   const char* env_big = getenv("SKHIP_GEMM_BIG");
-  bool use_big = in_dtype == SK_BF16 && fast && layout == SK_GEMM_NT && !use_staged &&
-                 ((M + 255) / 256) * ((N + 255) / 256) >= 8 * sk_num_cus();
+  bool use_big = false;
+  if (in_dtype == SK_BF16 && fast && layout == SK_GEMM_NT && !use_staged) {
+    const int64_t t256 = ((M + 255) / 256) * ((N + 255) / 256), ncu = sk_num_cus();
+    const int64_t rounds = (t256 + ncu - 1) / ncu;
+    const double fill = (double)t256 / (double)(rounds * ncu);
+    use_big = t256 >= 8 * ncu || (K >= 1024 && fill >= 0.7) || (rounds == 1 && fill >= 0.7);
+  }
   if (env_big && env_big[0] == '0') use_big = false;
   if (env_big && env_big[0] == '1') use_big = in_dtype == SK_BF16 && fast && layout == SK_GEMM_NT;
   if (use_big) {

@@ -8,7 +8,14 @@ sys.path.insert(0, ROOT)
 from specialk_amd import _lib as L
 
 T, d, F, V = 33280, 512, 2048, 35000
+P = 25472
 SHAPES = [
+    ("sq NT 8192^3", 0, 8192, 8192, 8192, torch.bfloat16),
+    ("gen NT Px35000x512", 0, P, V, d, torch.bfloat16),
+    ("gendx NT Px512x35000", 0, P, d, V, torch.bfloat16),
+    ("genw TN 35000x512xP", 2, V, d, P, torch.float32),
+    ("ffn2 NT Px512x2048", 0, P, d, F, torch.bfloat16),
+    ("qkv NT Px1536x512", 0, P, 3 * d, d, torch.bfloat16),
     ("fwd  NT T x512 x512", 0, T, d, d, torch.bfloat16),
     ("ffn1 NT T x2048x512", 0, T, F, d, torch.bfloat16),
     ("ffn2 NT T x512 x2048", 0, T, d, F, torch.bfloat16),
@@ -22,7 +29,8 @@ SHAPES = [
     ("wgrad TN 2048x512 xT", 2, F, d, T, torch.float32),
     ("wgrad TN 512 x2048xT", 2, d, F, T, torch.float32),
 ]
-VARIANTS = [("small", {"SKHIP_GEMM_BIG": "0"}), ("big", {"SKHIP_GEMM_BIG": "1"})]
+VARIANTS = [("small g1", {"SKHIP_GEMM_BIG": "0", "SKHIP_GEMM_GROUP": "1"}), ("small g8", {"SKHIP_GEMM_BIG": "0", "SKHIP_GEMM_GROUP": "8"}),
+            ("big g1", {"SKHIP_GEMM_BIG": "1", "SKHIP_GEMM_GROUP": "1"}), ("big g8", {"SKHIP_GEMM_BIG": "1", "SKHIP_GEMM_GROUP": "8"})]
 only = sys.argv[1] if len(sys.argv) > 1 else ""
 dev = "cuda"
 g = torch.Generator(device=dev).manual_seed(0)
@@ -61,5 +69,5 @@ for name, layout, M, N, K, odt in SHAPES:
     line = f"{name:28s}"
     for v, _ in VARIANTS:
         t = sorted(times[v])
-        line += f" | {v}: med {t[2]:8.1f} us min {t[0]:8.1f} us {fl / t[2] / 1e6:7.1f} TF err {errs[v]:.1e}"
+        line += f" | {v}: {t[2]:7.1f} us {fl / t[2] / 1e6:6.0f} TF e{errs[v]:.0e}"
     print(line, flush=True)
