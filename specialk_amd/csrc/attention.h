@@ -52,12 +52,24 @@ __device__ __forceinline__ bool masked(const AttnParams& p, const Seq& sq, int b
   if (p.dense && p.dense[((int64_t)b * p.Lq + i) * p.Lk + j]) return true;
   return false;
 }
+// Dropout on the probabilities: element (b, h, i, j) is half j & 1 of pair
+// ((b*H + h)*Lq + i) * ceil(Lk/2) + j/2, so that two neighbouring keys of a row share one hash.
+__device__ __forceinline__ uint64_t keep_row(const AttnParams& p, int b, int h, int i) {
+  return (((uint64_t)b * p.H + h) * p.Lq + i) * (uint64_t)((p.Lk + 1) >> 1);
+}
 __device__ __forceinline__ bool keep(const AttnParams& p, int b, int h, int i, int j) {
   if (!p.drop_thr) return true;
-  uint64_t idx = (((uint64_t)b * p.H + h) * p.Lq + i) * p.Lk + j;
-  return sk_keep(p.seed, idx, p.drop_thr);
+  return sk_keep_half(sk_hash_pair(sk_seed(p.seed), keep_row(p, b, h, i) + (j >> 1)), j & 1, p.drop_thr);
 }
-
+// keys j4 .. j4+3 (j4 a multiple of 4) of one row: bit r = keep key j4 + r
+__device__ __forceinline__ uint32_t keep4(const AttnParams& p, int b, int h, int i, int j4) {
+  if (!p.drop_thr) return 15u;
+  const SkSeed sd = sk_seed(p.seed);
+  const uint64_t base = keep_row(p, b, h, i) + (j4 >> 1);
+  const uint32_t r0 = sk_hash_pair(sd, base), r1 = sk_hash_pair(sd, base + 1);
+  return (uint32_t)sk_keep_half(r0, 0, p.drop_thr) | ((uint32_t)sk_keep_half(r0, 1, p.drop_thr) << 1) |
+         ((uint32_t)sk_keep_half(r1, 0, p.drop_thr) << 2) | ((uint32_t)sk_keep_half(r1, 1, p.drop_thr) << 3);
+}
 
 }  // namespace skattn
 

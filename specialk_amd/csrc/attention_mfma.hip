@@ -140,14 +140,16 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(AttnParams p) {
     const float alpha = dead ? 1.f : __expf(m - mn);
     float rs = 0.f;
 #pragma unroll
-    for (int kt = 0; kt < 4; ++kt)
+    for (int kt = 0; kt < 4; ++kt) {
+      const uint32_t km = keep4(p, b, h, q, j0 + 16 * kt + 4 * g);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         float pr = dead ? 0.f : __expf(sc[kt][r] - mn);
         rs += pr;
-        if (p.drop_thr) pr = keep(p, b, h, q, j0 + 16 * kt + 4 * g + r) ? pr * p.keep_scale : 0.f;
+        if (p.drop_thr) pr = (km >> r) & 1 ? pr * p.keep_scale : 0.f;
         sc[kt][r] = pr;
       }
+    }
     l = l * alpha + quad_sum(rs);
     m = mn;
     const bf16x8_t y0 = pack_y(sc[0], sc[1]), y1 = pack_y(sc[2], sc[3]);
@@ -230,13 +232,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(AttnParams p) {
         sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x_rows<D>(Ks, 16 * kt, s, lane), fq[s], sc, 0, 0, 0);
         dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x_rows<D>(Vs, 16 * kt, s, lane), fdo[s], dp, 0, 0, 0);
       }
+      const uint32_t km = keep4(p, b, h, q, j0 + 16 * kt + 4 * g);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int jl = 16 * kt + 4 * g + r;
         const bool msk = kmask[jl] || (p.causal && j0 + jl > q) || q >= Lq;
         float pr = msk ? 0.f : __expf(sc[r] * p.scale - lse);
         float dpv = dp[r];
-        if (p.drop_thr) dpv = keep(p, b, h, q, j0 + jl) ? dpv * p.keep_scale : 0.f;
+        if (p.drop_thr) dpv = (km >> r) & 1 ? dpv * p.keep_scale : 0.f;
         ds[kt][r] = pr * (dpv - dl) * p.scale;
       }
     }

@@ -81,23 +81,37 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 // ------------------------------------------------------------------ counter-based RNG for dropout
-// A 64-bit mix (splitmix64 finaliser) of (seed, element index): stateless, so forward and
-// backward regenerate identical masks from the same (seed, index) with no stored mask.
-__device__ __forceinline__ uint32_t sk_hash(uint64_t seed, uint64_t idx) {
-  uint64_t z = seed + idx * 0x9E3779B97F4A7C15ull;
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  z = z ^ (z >> 31);
-  return (uint32_t)(z >> 32);
+// Stateless: forward and backward regenerate identical masks from (seed, element index) with no
+// stored mask.  One 32-bit mix (two multiply-xorshift rounds, keyed by both seed words) of a PAIR
+// index yields 16 random bits for each of two neighbouring elements; 64-bit multiplies and one
+// hash per element made the mask generation, not HBM, the cost of the LayerNorm kernels.
+struct SkSeed { uint32_t s0, s1; };
+__device__ __forceinline__ SkSeed sk_seed(uint64_t seed) {
+  SkSeed k;
+  k.s0 = (uint32_t)seed * 0x9E3779B1u + 0x7F4A7C15u;
+  k.s1 = (uint32_t)(seed >> 32) * 0x85EBCA77u + (uint32_t)seed;
+  return k;
 }
-// keep with probability 1-p
-__device__ __forceinline__ bool sk_keep(uint64_t seed, uint64_t idx, uint32_t drop_threshold) {
-  return sk_hash(seed, idx) >= drop_threshold;
+__device__ __forceinline__ uint32_t sk_hash_pair(SkSeed k, uint64_t pair) {
+  uint32_t x = (uint32_t)pair ^ k.s0;
+  x ^= x >> 16; x *= 0x7FEB352Du;
+  x ^= k.s1 + (uint32_t)(pair >> 32) * 0xC2B2AE3Du;
+  x ^= x >> 15; x *= 0x846CA68Bu;
+  x ^= x >> 16;
+  return x;
 }
+// element `half` (0 / 1) of the pair is kept with probability 1 - thr16 / 65536
+__device__ __forceinline__ bool sk_keep_half(uint32_t r, int half, uint32_t thr16) {
+  return (half ? (r >> 16) : (r & 0xFFFFu)) >= thr16;
+}
+__device__ __forceinline__ bool sk_keep(SkSeed k, uint64_t idx, uint32_t thr16) {
+  return sk_keep_half(sk_hash_pair(k, idx >> 1), (int)(idx & 1), thr16);
+}
+// drop probability p as a 16-bit threshold (0 = no dropout)
 static inline uint32_t sk_drop_threshold(float p) {
-  double t = (double)p * 4294967296.0;
-  if (t <= 0) return 0u;
-  if (t >= 4294967295.0) return 4294967295u;
+  double t = (double)p * 65536.0 + 0.5;
+  if (t < 1.0) return 0u;
+  if (t >= 65535.0) return 65535u;
   return (uint32_t)t;
 }
 

@@ -18,6 +18,21 @@ constexpr int LN_NPART = 3;  // dgamma, dbeta, colsum(dx)
 // not 32).  Every wave walks its rows two at a time and issues the loads of both rows before it
 // reduces either: with one row in flight per wave the kernels were latency bound at a third of
 // the HBM rate.
+// Keep bits of VN consecutive elements starting at the even element index `base` (bit j = keep
+// element base + j): one pair hash per two elements; all ones without dropout (keep_scale is 1).
+template <int VN>
+__device__ __forceinline__ uint32_t keep_mask(SkSeed sd, uint64_t base, uint32_t drop_thr) {
+  if (!drop_thr) return 0xFFFFFFFFu;
+  uint32_t m = 0;
+#pragma unroll
+  for (int jp = 0; jp < VN / 2; ++jp) {
+    const uint32_t r = sk_hash_pair(sd, (base >> 1) + jp);
+    m |= (uint32_t)sk_keep_half(r, 0, drop_thr) << (2 * jp);
+    m |= (uint32_t)sk_keep_half(r, 1, drop_thr) << (2 * jp + 1);
+  }
+  return m;
+}
+
 template <typename T, int MAXV>
 __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const T* __restrict__ x, const T* __restrict__ res,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -29,6 +44,7 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const T* __restrict__ x
   typedef decltype(Vec16<T>().v) raw_t;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nvec = d / VN;  // vectors per row
+  const SkSeed sd = sk_seed(seed);
   const int64_t stride = (int64_t)gridDim.x * 4;
   for (int64_t row0 = (int64_t)blockIdx.x * 4 + wave; row0 < T_rows; row0 += 2 * stride) {
     Vec16<T> a[2][MAXV], b[2][MAXV];
@@ -54,14 +70,15 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const T* __restrict__ x
 #pragma unroll
       for (int v = 0; v < MAXV; ++v) {
         const int vi = lane + v * 64;
-        if (vi < nvec)
+        if (vi < nvec) {
+          const uint32_t km = keep_mask<VN>(sd, (uint64_t)(row * d + vi * VN), drop_thr);
 #pragma unroll
           for (int j = 0; j < VN; ++j) {
-            float xv = a[r][v].get(j);
-            if (drop_thr) xv = sk_keep(seed, (uint64_t)(row * d + vi * VN + j), drop_thr) ? xv * keep_scale : 0.f;
+            const float xv = (km >> j) & 1 ? a[r][v].get(j) * keep_scale : 0.f;
             z[v][j] = b[r][v].get(j) + xv;
             sum += z[v][j];
           }
+        }
       }
       const float mean = wave_sum(sum) / (float)d;
       float sq = 0.f;
@@ -118,6 +135,7 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const T* __restrict__ d
   float* red = (float*)smem_raw;  // [4 waves][3][d]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nvec = d / VN;
+  const SkSeed sd = sk_seed(seed);
   float pg[MAXV][VN], pb[MAXV][VN], px[MAXV][VN], gm[MAXV][VN];
 #pragma unroll
   for (int v = 0; v < MAXV; ++v)
@@ -158,15 +176,16 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const T* __restrict__ d
       const bool pad = pad_r[r];
       const float mean = mean_r[r], rstd = rstd_r[r];
       float xhat[MAXV][VN], dxh[MAXV][VN];
+      uint32_t km[MAXV];
       float s1 = 0.f, s2 = 0.f;
 #pragma unroll
       for (int v = 0; v < MAXV; ++v) {
         const int vi = lane + v * 64;
-        if (vi < nvec)
+        if (vi < nvec) {
+          km[v] = keep_mask<VN>(sd, (uint64_t)(row * d + vi * VN), drop_thr);
 #pragma unroll
           for (int j = 0; j < VN; ++j) {
-            float xv = a[r][v].get(j);
-            if (drop_thr) xv = sk_keep(seed, (uint64_t)(row * d + vi * VN + j), drop_thr) ? xv * keep_scale : 0.f;
+            const float xv = (km[v] >> j) & 1 ? a[r][v].get(j) * keep_scale : 0.f;
             const float xh = (b[r][v].get(j) + xv - mean) * rstd;
             const float dyv = pad ? 0.f : g[r][v].get(j);
             const float dh = dyv * gm[v][j];
@@ -177,6 +196,7 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const T* __restrict__ d
             s1 += dh;
             s2 += dh * xh;
           }
+        }
       }
       const float c1 = wave_sum(s1) / (float)d, c2 = wave_sum(s2) / (float)d;
 #pragma unroll
@@ -188,8 +208,7 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const T* __restrict__ d
           for (int j = 0; j < VN; ++j) {
             const float dz = rstd * (dxh[v][j] - c1 - xhat[v][j] * c2);
             o1.set(j, dz);
-            float dxv = dz;
-            if (drop_thr) dxv = sk_keep(seed, (uint64_t)(row * d + vi * VN + j), drop_thr) ? dz * keep_scale : 0.f;
+            const float dxv = (km[v] >> j) & 1 ? dz * keep_scale : 0.f;
             o2.set(j, dxv);
             px[v][j] += dxv;
           }
@@ -219,23 +238,33 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const T* __restrict__ d
   }
 }
 
-// 64 columns x 4 row-lanes per block; each row-lane adds every 4th block's partial.
-__global__ __launch_bounds__(256) void ln_param_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dgamma,
-                                                              float* __restrict__ dbeta, float* __restrict__ dxsum, int d,
-                                                              int nblocks, int accumulate) {
-  __shared__ float part[4][64];
+// 64 columns x 16 row-lanes per block; row-lane q adds partials q, q+16, ... (four independent
+// chains of loads in flight), then the 16 lane sums are combined in a fixed tree.
+__global__ __launch_bounds__(1024) void ln_param_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dgamma,
+                                                               float* __restrict__ dbeta, float* __restrict__ dxsum, int d,
+                                                               int nblocks, int accumulate) {
+  __shared__ float part[16][64];
   const int nd = LN_NPART * d;
-  const int i = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
-  float s0 = 0.f, s1 = 0.f;
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + cl;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   if (i < nd) {
     int b = rl;
-    for (; b + 4 < nblocks; b += 8) { s0 += partial[(int64_t)b * nd + i]; s1 += partial[(int64_t)(b + 4) * nd + i]; }
-    if (b < nblocks) s0 += partial[(int64_t)b * nd + i];
+    for (; b + 48 < nblocks; b += 64) {
+      s0 += partial[(int64_t)b * nd + i];
+      s1 += partial[(int64_t)(b + 16) * nd + i];
+      s2 += partial[(int64_t)(b + 32) * nd + i];
+      s3 += partial[(int64_t)(b + 48) * nd + i];
+    }
+    for (; b < nblocks; b += 16) s0 += partial[(int64_t)b * nd + i];
   }
-  part[rl][threadIdx.x & 63] = s0 + s1;
+  part[rl][cl] = (s0 + s1) + (s2 + s3);
   __syncthreads();
   if (rl == 0 && i < nd) {
-    float s = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+    float t[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t[k] = part[2 * k][cl] + part[2 * k + 1][cl];
+    const float s = ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
     float* out = i < d ? dgamma + i : (i < 2 * d ? dbeta + (i - d) : (dxsum ? dxsum + (i - 2 * d) : nullptr));
     if (out) *out = (accumulate && i < 2 * d) ? *out + s : s;
   }
@@ -310,7 +339,7 @@ extern "C" int skhip_add_ln_bwd(const void* dy, const void* x, const void* res, 
   }
 #undef LN_BWD
   SK_CHECK_LAUNCH("skhip_add_ln_bwd");
-  hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((LN_NPART * d + 63) / 64), dim3(256), 0, stream, partial_ws, dgamma,
+  hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((LN_NPART * d + 63) / 64), dim3(1024), 0, stream, partial_ws, dgamma,
                      dbeta, dx_colsum, d, (int)blocks, accumulate);
   SK_CHECK_LAUNCH("skhip_add_ln_bwd(param reduce)");
   return SK_OK;
