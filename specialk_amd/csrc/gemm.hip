@@ -949,7 +949,10 @@ extern "C" int skhip_gemm(int layout, const void* A, const void* B, void* C, con
   int splits = 1;
   const int cus = sk_num_cus();
   if (workspace && tiles < cus && K >= 8 * bk) {
-    int64_t want = (2 * cus + tiles - 1) / tiles;
+    // as many splits as fill the resident block slots of the chosen kernel WITHOUT spilling into a
+    // further, mostly empty round (48 tiles x 11 splits on 512 slots ran 3 rounds instead of 2)
+    const int64_t slots = (int64_t)cus * (in_dtype != SK_BF16 ? 2 : use_big ? 1 : (fast && !use_staged) ? 3 : 2);
+    int64_t want = slots / tiles;
     int64_t max_by_k = K / (4 * bk);
     int64_t max_by_ws = workspace_bytes / (int64_t)(M * N * 4);
     int64_t s = want < max_by_k ? want : max_by_k;

@@ -47,7 +47,7 @@ class MultiHeadAttention(nn.Module):
         out, attn = ops.MHAFn.apply(q_in, kv_in, self.w_qs.weight, self.w_qs.bias, self.w_ks.weight, self.w_ks.bias,
                                     self.w_vs.weight, self.w_vs.bias, self.fc.weight, self.fc.bias, cfg)
         y = ops.add_ln(out, q_in, self.layer_norm.weight, self.layer_norm.bias, row_pad, self.layer_norm.eps,
-                       self.dropout.p if training else 0.0)
+                       self.dropout.p if training else 0.0, res_feeds_x=True)
         return y, attn
 
     # -- reference interface
@@ -92,7 +92,7 @@ class PositionwiseFeedForward(nn.Module):
     def forward_2d(self, x, row_pad=None):
         y = ops.FFNFn.apply(x, self.w_1.weight, self.w_1.bias, self.w_2.weight, self.w_2.bias)
         return ops.add_ln(y, x, self.layer_norm.weight, self.layer_norm.bias, row_pad, self.layer_norm.eps,
-                          self.dropout.p if self.training else 0.0)
+                          self.dropout.p if self.training else 0.0, res_feeds_x=True)
 
     def forward(self, x):
         shape = x.shape

@@ -167,19 +167,28 @@ def _bias_grad(dy, T, N):
     return L.colsum(dy, T, N, N)
 
 
+def _residual_grad(dy):
+    """The residual-branch gradient that AddLNFn.backward attached to dy (see there), or None."""
+    pre = getattr(dy, "_sk_dres", None)
+    return pre[1] if pre is not None and pre[0] == dy.data_ptr() else None
+
+
 def _w2d(w):
     return w.reshape(w.shape[0], -1)  # Conv1d(k=1) weights (out,in,1) are linear maps (out,in)
 
 
-def _input_grad(dy, ldy, Ws, T, d_in, dt, alpha=1.0, aux=None, epilogue=0):
+def _input_grad(dy, ldy, Ws, T, d_in, dt, alpha=1.0, aux=None, epilogue=0, add_to=None):
     """dx (T, d_in) = alpha * dy (T, sum n_i; row stride ldy) @ [W_1; W_2; ...] for weights W_i (n_i, d_in).
-    bf16: ONE GEMM against the K-contiguous transposed copy; fp32: one exact-fp32 GEMM per weight."""
+    bf16: ONE GEMM against the K-contiguous transposed copy; fp32: one exact-fp32 GEMM per weight.
+    add_to: a (T, d_in) tensor the result is accumulated into (and which is returned)."""
     n_tot = sum(_as2d(w)[0] for w in Ws)
     if dt == torch.bfloat16:
         return L.gemm(L.GEMM_NT, dy, derived_weight("catT", Ws), T, d_in, n_tot, ldy, n_tot, alpha=alpha, aux=aux,
-                      epilogue=epilogue)
+                      epilogue=epilogue | (L.EPI_ACCUM if add_to is not None else 0), out=add_to,
+                      ldc=None if add_to is None else d_in)
     assert len(Ws) == 1 or (aux is None and epilogue == 0)
-    dx, off = None, 0
+    assert add_to is None or (aux is None and epilogue == 0)
+    dx, off = add_to, 0
     for w in Ws:
         n = _as2d(w)[0]
         if dx is None:
@@ -261,13 +270,14 @@ class FFNFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x, h, W1, W2 = ctx.saved_tensors
+        dres = _residual_grad(dy)
         dy = dy.contiguous()
         T, d = x.shape
         F = _as2d(W1)[0]
         dh = _input_grad(dy, d, (W2,), T, F, x.dtype, aux=h, epilogue=L.EPI_RELU_MASK)
         dW2 = L.gemm(L.GEMM_TN, dy, h, d, F, T, d, F, out_dtype=torch.float32).view(W2.shape)
         db2 = _bias_grad(dy, T, d)
-        dx = _input_grad(dh, F, (W1,), T, d, x.dtype)
+        dx = _input_grad(dh, F, (W1,), T, d, x.dtype, add_to=dres)  # dy is not read after this line
         dW1 = L.gemm(L.GEMM_TN, dh, x, F, d, T, F, x.stride(0), out_dtype=torch.float32).view(W1.shape)
         db1 = L.colsum(dh, T, F, F)
         return dx, dW1, db1, dW2, db2
@@ -329,6 +339,7 @@ class MHAFn(torch.autograd.Function):
         Tq, Tk = q_in.shape[0], kv_in.shape[0]
         nq, nk, nv = H * dk, H * dk, H * dv
         ldq, ldk, ldv = ctx.lds
+        dres = _residual_grad(dout)
         dout = dout.contiguous()
         f32 = torch.float32
         # output projection
@@ -357,7 +368,7 @@ class MHAFn(torch.autograd.Function):
             db = L.colsum(dqkv, Tq, n3, lddq)
             dWq, dWk, dWv = dW[:nq], dW[nq:nq + nk], dW[nq + nk:]
             dbq, dbk, dbv = db[:nq], db[nq:nq + nk], db[nq + nk:]
-            dq_in = _input_grad(dqkv, lddq, (Wq, Wk, Wv), Tq, d, dt)
+            dq_in = _input_grad(dqkv, lddq, (Wq, Wk, Wv), Tq, d, dt, add_to=dres)  # dout is not read after this
             dkv_in = None
         else:
             dWq = L.gemm(L.GEMM_TN, dQ, q_in, nq, d, Tq, lddq, q_in.stride(0), out_dtype=f32)
@@ -365,7 +376,7 @@ class MHAFn(torch.autograd.Function):
             dW = L.gemm(L.GEMM_TN, dkv, kv_in, nk + nv, d, Tk, lddk, kv_in.stride(0), out_dtype=f32)
             db = L.colsum(dkv, Tk, nk + nv, lddk)
             dWk, dWv, dbk, dbv = dW[:nk], dW[nk:], db[:nk], db[nk:]
-            dq_in = _input_grad(dQ, lddq, (Wq,), Tq, d, dt)
+            dq_in = _input_grad(dQ, lddq, (Wq,), Tq, d, dt, add_to=dres)  # dout is not read after this
             dkv_in = _input_grad(dkv, lddk, (Wk, Wv), Tk, d, dt)
         return dq_in, dkv_in, dWq, dbq, dWk, dbk, dWv, dbv, dWo, dbo, None
 
@@ -410,12 +421,13 @@ class AddLNFn(torch.autograd.Function):
     and the `*= non_pad_mask` of lib/transformer/Layers.py)."""
 
     @staticmethod
-    def forward(ctx, x, res, gamma, beta, row_pad, eps, p_drop):
+    def forward(ctx, x, res, gamma, beta, row_pad, eps, p_drop, res_feeds_x):
         seed = next_seed() if p_drop > 0 else 0
         x, res = x.contiguous(), res.contiguous()
         y, mean, rstd = L.add_ln_fwd(x, res, gamma.detach(), beta.detach(), row_pad, eps, p_drop, seed)
         ctx.save_for_backward(x, res, gamma, mean, rstd)
         ctx.row_pad, ctx.p_drop, ctx.seed = row_pad, p_drop, seed
+        ctx.res_feeds_x = res_feeds_x and ctx.needs_input_grad[1]
         return y
 
     @staticmethod
@@ -426,11 +438,19 @@ class AddLNFn(torch.autograd.Function):
         if dx.data_ptr() == dres.data_ptr():
             dx = dx.view(dx.shape)  # distinct tensor object for the x-branch gradient
         dx._sk_colsum = (dx.data_ptr(), dxs)  # bias gradient of the linear layer that produced x
-        return dx, dres, dg, db, None, None, None
+        if ctx.res_feeds_x:
+            # x = f(res) with f an MHAFn / FFNFn: hand the residual-branch gradient to f's backward,
+            # whose last GEMM accumulates the input gradient into it, instead of returning it here
+            # and letting autograd add the two (T, d) tensors in a separate pass.
+            dx._sk_dres = (dx.data_ptr(), dres)
+            dres = None
+        return dx, dres, dg, db, None, None, None, None
 
 
-def add_ln(x, res, gamma, beta, row_pad=None, eps=1e-5, p_drop=0.0):
-    return AddLNFn.apply(x, res, gamma, beta, row_pad, eps, p_drop)
+def add_ln(x, res, gamma, beta, row_pad=None, eps=1e-5, p_drop=0.0, res_feeds_x=False):
+    """res_feeds_x=True promises that x was produced from res by ONE MHAFn (as its q_in) or FFNFn call
+    and is used by nothing else; the residual gradient is then folded into that call's backward."""
+    return AddLNFn.apply(x, res, gamma, beta, row_pad, eps, p_drop, res_feeds_x)
 
 
 # ----------------------------------------------------------------------------- embeddings
