@@ -20,7 +20,7 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const T* __restrict__ 
                                                           const int32_t* __restrict__ kv_len,
                                                           const uint8_t* __restrict__ key_pad, int R, int H, int len,
                                                           int Lmax, int dk, int dv, int64_t ldq, int64_t ldo, float scale,
-                                                          int kv_row_div) {
+                                                          int kv_row_div, int vec_k, int vec_v) {
   __shared__ float qs[4][128];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int pair = blockIdx.x * 4 + wave;
@@ -35,13 +35,32 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const T* __restrict__ 
   const T* Vr = Vc + (int64_t)kr_row * Lmax * H * dv + h * dv;
   float m = -INFINITY, l = 0.f, acc0 = 0.f, acc1 = 0.f;
   const int c0 = lane < dv ? lane : 0, c1 = lane + 64 < dv ? lane + 64 : 0;
+  // P.V with 16-byte loads: lane = (row group rg, column chunk ch); a lane accumulates its VN columns
+  // over rows rg, rg + nrg, ... of every tile (independent loads, all in flight together) and the
+  // row groups are summed across lanes once at the end.
+  constexpr int VN = Vec16<T>::N;
+  const int nch = vec_v ? dv / VN : 1, nrg = 64 / nch;
+  const int ch = lane & (nch - 1), rg = lane / nch;
+  float accv[VN];
+#pragma unroll
+  for (int e = 0; e < VN; ++e) accv[e] = 0.f;
   for (int j0 = 0; j0 < n; j0 += 64) {
     const int j = j0 + lane;
     float s = -INFINITY;
     if (j < n && !(key_pad && key_pad[(int64_t)kr_row * Lmax + j])) {
       const T* kr = Kr + (int64_t)j * H * dk;
       float a = 0.f;
-      for (int c = 0; c < dk; ++c) a += qs[wave][c] * Cvt<T>::to_f32(kr[c]);
+      if (vec_k) {  // 16-byte loads of the lane's key row
+        constexpr int VN = Vec16<T>::N;
+        for (int c = 0; c < dk; c += VN) {
+          Vec16<T> kv;
+          kv.v = *(const decltype(kv.v)*)(kr + c);
+#pragma unroll
+          for (int e = 0; e < VN; ++e) a += qs[wave][c + e] * kv.get(e);
+        }
+      } else {
+        for (int c = 0; c < dk; ++c) a += qs[wave][c] * Cvt<T>::to_f32(kr[c]);
+      }
       s = a;
     }
     float mn = fmaxf(m, wave_max(s));
@@ -49,6 +68,23 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const T* __restrict__ 
     if (mn != -INFINITY) { alpha = expf(m - mn); pr = expf(s - mn); }
     l = l * alpha + wave_sum(pr);
     m = mn;
+    if (vec_v) {
+#pragma unroll
+      for (int e = 0; e < VN; ++e) accv[e] *= alpha;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {  // nch <= 16 for dv <= 128
+        if (i >= nch) break;
+        const int t = rg + nrg * i;
+        const float cf = __shfl(pr, t, 64);
+        if (j0 + t < n) {
+          Vec16<T> vv;
+          vv.v = *(const decltype(vv.v)*)(Vr + (int64_t)(j0 + t) * H * dv + ch * VN);
+#pragma unroll
+          for (int e = 0; e < VN; ++e) accv[e] += cf * vv.get(e);
+        }
+      }
+      continue;
+    }
     acc0 *= alpha; acc1 *= alpha;
     const int cnt = min(64, n - j0);
     for (int t = 0; t < cnt; ++t) {
@@ -59,6 +95,18 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const T* __restrict__ 
     }
   }
   const float inv = 1.0f / l;
+  if (vec_v) {
+    for (int o = nch; o < 64; o <<= 1)
+#pragma unroll
+      for (int e = 0; e < VN; ++e) accv[e] += __shfl_xor(accv[e], o, 64);
+    if (rg == 0) {
+      Vec16<T> ov;
+#pragma unroll
+      for (int e = 0; e < VN; ++e) ov.set(e, accv[e] * inv);
+      *(decltype(ov.v)*)(out + (int64_t)r * ldo + h * dv + ch * VN) = ov.v;
+    }
+    return;
+  }
   if (lane < dv) out[(int64_t)r * ldo + h * dv + lane] = Cvt<T>::from_f32(acc0 * inv);
   if (lane + 64 < dv) out[(int64_t)r * ldo + h * dv + lane + 64] = Cvt<T>::from_f32(acc1 * inv);
 }
@@ -103,11 +151,10 @@ __global__ __launch_bounds__(256) void beam_row_topk_kernel(const float* __restr
 #pragma unroll
   for (int k = 0; k < KC; ++k) { tv[k] = -INFINITY; ti[k] = 0x7fffffff; }
   float mx = -INFINITY;
-  for (int64_t c = threadIdx.x; c < V; c += 256) {
-    float v = x[c];
+  auto visit = [&](float v, int c) {
     mx = fmaxf(mx, v);
-    if (better(v, (int)c, tv[KC - 1], ti[KC - 1])) {
-      tv[KC - 1] = v; ti[KC - 1] = (int)c;
+    if (better(v, c, tv[KC - 1], ti[KC - 1])) {
+      tv[KC - 1] = v; ti[KC - 1] = c;
 #pragma unroll
       for (int k = KC - 1; k > 0; --k)
         if (better(tv[k], ti[k], tv[k - 1], ti[k - 1])) {
@@ -115,6 +162,24 @@ __global__ __launch_bounds__(256) void beam_row_topk_kernel(const float* __restr
           int fi = ti[k]; ti[k] = ti[k - 1]; ti[k - 1] = fi;
         }
     }
+  };
+  const bool vec = (V & 3) == 0 && ((uintptr_t)x & 15) == 0;
+  if (vec) {  // two 16-byte loads in flight per thread
+    const float4* x4 = (const float4*)x;
+    const int64_t n4 = V >> 2;
+    int64_t c = threadIdx.x;
+    for (; c + 256 < n4; c += 512) {
+      const float4 a = x4[c], b = x4[c + 256];
+      visit(a.x, (int)(4 * c)); visit(a.y, (int)(4 * c + 1)); visit(a.z, (int)(4 * c + 2)); visit(a.w, (int)(4 * c + 3));
+      const int64_t e = c + 256;
+      visit(b.x, (int)(4 * e)); visit(b.y, (int)(4 * e + 1)); visit(b.z, (int)(4 * e + 2)); visit(b.w, (int)(4 * e + 3));
+    }
+    for (; c < n4; c += 256) {
+      const float4 a = x4[c];
+      visit(a.x, (int)(4 * c)); visit(a.y, (int)(4 * c + 1)); visit(a.z, (int)(4 * c + 2)); visit(a.w, (int)(4 * c + 3));
+    }
+  } else {
+    for (int64_t c = threadIdx.x; c < V; c += 256) visit(x[c], (int)c);
   }
   mx = wave_max(mx);
   if (lane == 0) s_red[wave] = mx;
@@ -124,7 +189,17 @@ __global__ __launch_bounds__(256) void beam_row_topk_kernel(const float* __restr
   float logse = 0.f;
   if (normalize) {
     float se = 0.f;
-    for (int64_t c = threadIdx.x; c < V; c += 256) se += expf(x[c] - mx);
+    if (vec) {
+      const float4* x4 = (const float4*)x;
+      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+      for (int64_t c = threadIdx.x; c < (V >> 2); c += 256) {
+        const float4 a = x4[c];
+        s0 += expf(a.x - mx); s1 += expf(a.y - mx); s2 += expf(a.z - mx); s3 += expf(a.w - mx);
+      }
+      se = (s0 + s1) + (s2 + s3);
+    } else {
+      for (int64_t c = threadIdx.x; c < V; c += 256) se += expf(x[c] - mx);
+    }
     se = wave_sum(se);
     if (lane == 0) s_red[wave] = se;
     __syncthreads();
@@ -235,13 +310,18 @@ extern "C" int skhip_decode_attn(const void* q, const void* Kc, const void* Vc, 
   if (R == 0) return SK_OK;
   SK_CHECK_ARG(q && Kc && Vc && out, "skhip_decode_attn: null pointer");
   unsigned blocks = (unsigned)(((int64_t)R * n_head + 3) / 4);
+  const int vn = dtype == SK_BF16 ? 8 : 4;
+  const int vec_k = (dk % vn == 0) && ((uintptr_t)Kc % 16 == 0);  // key rows start on 16-byte boundaries
+  const int nch = dv / vn;                                          // 16-byte column chunks of a value row
+  const int vec_v = (dv % vn == 0) && nch <= 16 && (nch & (nch - 1)) == 0 && ((uintptr_t)Vc % 16 == 0) &&
+                    ((uintptr_t)out % 16 == 0) && (ldo % vn == 0);
   if (dtype == SK_BF16)
     hipLaunchKernelGGL((decode_attn_kernel<bf16_t>), dim3(blocks), dim3(256), 0, stream, (const bf16_t*)q,
                        (const bf16_t*)Kc, (const bf16_t*)Vc, (bf16_t*)out, kv_len, key_pad, R, n_head, len, Lmax, dk, dv,
-                       ldq, ldo, scale, kv_row_div);
+                       ldq, ldo, scale, kv_row_div, vec_k, vec_v);
   else
     hipLaunchKernelGGL((decode_attn_kernel<float>), dim3(blocks), dim3(256), 0, stream, (const float*)q, (const float*)Kc,
-                       (const float*)Vc, (float*)out, kv_len, key_pad, R, n_head, len, Lmax, dk, dv, ldq, ldo, scale, kv_row_div);
+                       (const float*)Vc, (float*)out, kv_len, key_pad, R, n_head, len, Lmax, dk, dv, ldq, ldo, scale, kv_row_div, vec_k, vec_v);
   SK_CHECK_LAUNCH("skhip_decode_attn");
   return SK_OK;
 }

@@ -88,8 +88,10 @@ class BeamDecoder:
 
         def proj(x, lin, out=None, ldc=None, relu=False):
             w = self._w(lin.weight, dt)
+            # a (R, 512) output is a handful of tiles: split-K only pays for the long contraction of w_2,
+            # elsewhere its slab write + reduce launch costs more than it saves
             return L.gemm(L.GEMM_NT, x, w, R, w.shape[0], w.shape[1], x.stride(0), w.shape[1], out=out, ldc=ldc,
-                          bias=lin.bias.detach(), epilogue=L.EPI_RELU if relu else 0)
+                          bias=lin.bias.detach(), epilogue=L.EPI_RELU if relu else 0, split_k=w.shape[1] >= 2048)
 
         def add_ln(o, x, ln, row_pad):
             y, _, _ = L.add_ln_fwd(o, x, ln.weight.detach(), ln.bias.detach(), row_pad, ln.eps, 0.0, 0)
