@@ -104,12 +104,14 @@ _workspaces = {}
 
 
 def workspace(nbytes=64 << 20, device=None):
-    """Persistent scratch per device (split-K slabs, LayerNorm partials, beam candidates)."""
+    """Persistent scratch per device and stream (split-K slabs, LayerNorm partials, beam candidates):
+    kernels enqueued on different streams may run concurrently and must not share scratch."""
     device = torch.device("cuda", torch.cuda.current_device()) if device is None else device
-    ws = _workspaces.get(device)
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    ws = _workspaces.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(max(nbytes, 64 << 20), dtype=torch.uint8, device=device)
-        _workspaces[device] = ws
+        _workspaces[key] = ws
     return ws
 
 
