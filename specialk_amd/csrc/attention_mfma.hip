@@ -354,6 +354,169 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(AttnParams p) {
   }
 }
 
+// ------------------------------------------------------------------------------ dQ, dK, dV in one pass
+// Sequences of at most 64 positions (one tile on either side): one block per (batch, head) stages
+// Q, K, V and dO once and produces all three gradients — phase A with the waves' own QUERY rows
+// (delta, dS, dQ), phase B with their own KEY rows (dV, dK) — instead of two launches that each
+// re-read every operand from HBM.
+template <int D>
+__global__ __launch_bounds__(256) void attn_bwd_fused_mfma_kernel(AttnParams p) {
+  __shared__ __attribute__((aligned(16))) Tile<D> Ks;
+  __shared__ __attribute__((aligned(16))) Tile<D> Vs;
+  __shared__ __attribute__((aligned(16))) Tile<D> Qs;
+  __shared__ __attribute__((aligned(16))) Tile<D> dOs;
+  __shared__ uint8_t kmask[OT];
+  __shared__ float s_lse[OT], s_dl[OT];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int c = lane & 15, g = lane >> 4;
+  const int own = wave * 16 + c;  // own query row (phase A) / own key row (phase B)
+  const Seq sq = seq_of(p, b);
+  const int Lq = sq.Lq, Lk = sq.Lk;
+  if (Lq <= 0 || Lk <= 0) return;  // block-uniform
+  stage_tile<D>(Ks, (const bf16_t*)p.K + sq.kbase * p.ldk + h * D, p.ldk, 0, Lk);
+  stage_tile<D>(Vs, (const bf16_t*)p.V + sq.kbase * p.ldv + h * D, p.ldv, 0, Lk);
+  stage_tile<D>(Qs, (const bf16_t*)p.Q + sq.qbase * p.ldq + h * D, p.ldq, 0, Lq);
+  stage_tile<D>(dOs, (const bf16_t*)p.dO + sq.qbase * p.ldo + h * D, p.ldo, 0, Lq);
+  if (threadIdx.x < OT) {
+    const int j = threadIdx.x;
+    kmask[j] = (j >= Lk) || (p.key_pad && p.key_pad[(int64_t)b * p.Lk + j]);
+  }
+  // delta = rowsum(dO * O) and LSE of the own query row
+  {
+    const int qrow = min(own, Lq - 1);
+    const bf16_t* O = (const bf16_t*)p.O + (sq.qbase + qrow) * p.ldo + h * D;
+    const bf16_t* dO = (const bf16_t*)p.dO + (sq.qbase + qrow) * p.ldo + h * D;
+    float dl = 0.f;
+#pragma unroll
+    for (int s = 0; s < D / 32; ++s) {
+      const bf16x8_t fo = ld_frag_global(O + 32 * s + 8 * g), fd = ld_frag_global(dO + 32 * s + 8 * g);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) dl += (float)fd[j] * (float)fo[j];
+    }
+    dl = quad_sum(dl);
+    if (g == 0) {
+      s_dl[own] = dl;
+      s_lse[own] = p.LSE[((int64_t)b * p.H + h) * p.Lq + qrow];
+    }
+  }
+  __syncthreads();
+
+  // ---- phase A: own query rows -> dQ
+  {
+    const int q = own;
+    bf16x8_t fq[D / 32], fdo[D / 32];
+#pragma unroll
+    for (int s = 0; s < D / 32; ++s) {
+      fq[s] = *(const bf16x8_t*)&Qs.a[q][32 * s + 8 * g];
+      fdo[s] = *(const bf16x8_t*)&dOs.a[q][32 * s + 8 * g];
+    }
+    const float lse = s_lse[q], dl = s_dl[q];
+    f32x4_t ds[4];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      f32x4_t sc = f32x4_t{0.f, 0.f, 0.f, 0.f}, dp = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < D / 32; ++s) {
+        sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x_rows<D>(Ks, 16 * kt, s, lane), fq[s], sc, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x_rows<D>(Vs, 16 * kt, s, lane), fdo[s], dp, 0, 0, 0);
+      }
+      const uint32_t km = keep4(p, b, h, q, 16 * kt + 4 * g);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int jl = 16 * kt + 4 * g + r;
+        const bool msk = kmask[jl] || (p.causal && jl > q) || q >= Lq;
+        const float pr = msk ? 0.f : __expf(sc[r] * p.scale - lse);
+        float dpv = dp[r];
+        if (p.drop_thr) dpv = (km >> r) & 1 ? dpv * p.keep_scale : 0.f;
+        ds[kt][r] = pr * (dpv - dl) * p.scale;
+      }
+    }
+    const bf16x8_t y0 = pack_y(ds[0], ds[1]), y1 = pack_y(ds[2], ds[3]);
+    // the transposing LDS reads need every lane active: multiply first, guard only the stores
+    f32x4_t dq[D / 16];
+#pragma unroll
+    for (int t = 0; t < D / 16; ++t) {
+      dq[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      dq[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x_cols<D>(Ks, 16 * t, 0, lane), y0, dq[t], 0, 0, 0);
+      dq[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x_cols<D>(Ks, 16 * t, 1, lane), y1, dq[t], 0, 0, 0);
+    }
+    if (q < Lq) {
+      bf16_t* out = (bf16_t*)p.dQ + (sq.qbase + q) * p.lddq + h * D;
+#pragma unroll
+      for (int t = 0; t < D / 16; ++t) {
+        uint2 w;
+        bf16_t* e = (bf16_t*)&w;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) e[r] = f32_to_bf16(dq[t][r]);
+        *(uint2*)(out + 16 * t + 4 * g) = w;
+      }
+    }
+  }
+
+  // ---- phase B: own key rows -> dK, dV
+  {
+    const int j = own;
+    bf16x8_t fk[D / 32], fv[D / 32];
+#pragma unroll
+    for (int s = 0; s < D / 32; ++s) {
+      fk[s] = *(const bf16x8_t*)&Ks.a[j][32 * s + 8 * g];
+      fv[s] = *(const bf16x8_t*)&Vs.a[j][32 * s + 8 * g];
+    }
+    const bool jmask = kmask[j];
+    f32x4_t pd[4], ds[4];
+#pragma unroll
+    for (int qt = 0; qt < 4; ++qt) {
+      f32x4_t sc = f32x4_t{0.f, 0.f, 0.f, 0.f}, dp = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < D / 32; ++s) {
+        sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x_rows<D>(Qs, 16 * qt, s, lane), fk[s], sc, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x_rows<D>(dOs, 16 * qt, s, lane), fv[s], dp, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = 16 * qt + 4 * g + r;
+        const bool msk = jmask || i >= Lq || (p.causal && j > i);
+        const float pr = msk ? 0.f : __expf(sc[r] * p.scale - s_lse[i]);
+        float dpv = dp[r], pdv = pr;
+        if (p.drop_thr) {
+          const bool kp = keep(p, b, h, i, j);
+          dpv = kp ? dpv * p.keep_scale : 0.f;
+          pdv = kp ? pr * p.keep_scale : 0.f;
+        }
+        pd[qt][r] = pdv;
+        ds[qt][r] = pr * (dpv - s_dl[i]) * p.scale;
+      }
+    }
+    const bf16x8_t yp0 = pack_y(pd[0], pd[1]), yp1 = pack_y(pd[2], pd[3]);
+    const bf16x8_t ys0 = pack_y(ds[0], ds[1]), ys1 = pack_y(ds[2], ds[3]);
+    f32x4_t dk[D / 16], dv[D / 16];
+#pragma unroll
+    for (int t = 0; t < D / 16; ++t) {
+      dv[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      dk[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      dv[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x_cols<D>(dOs, 16 * t, 0, lane), yp0, dv[t], 0, 0, 0);
+      dv[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x_cols<D>(dOs, 16 * t, 1, lane), yp1, dv[t], 0, 0, 0);
+      dk[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x_cols<D>(Qs, 16 * t, 0, lane), ys0, dk[t], 0, 0, 0);
+      dk[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x_cols<D>(Qs, 16 * t, 1, lane), ys1, dk[t], 0, 0, 0);
+    }
+    if (j < Lk) {
+      bf16_t* oK = (bf16_t*)p.dK + (sq.kbase + j) * p.lddk + h * D;
+      bf16_t* oV = (bf16_t*)p.dV + (sq.kbase + j) * p.lddv + h * D;
+#pragma unroll
+      for (int t = 0; t < D / 16; ++t) {
+        uint2 wk, wv;
+        bf16_t* ek = (bf16_t*)&wk;
+        bf16_t* ev = (bf16_t*)&wv;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { ek[r] = f32_to_bf16(dk[t][r]); ev[r] = f32_to_bf16(dv[t][r]); }
+        *(uint2*)(oK + 16 * t + 4 * g) = wk;
+        *(uint2*)(oV + 16 * t + 4 * g) = wv;
+      }
+    }
+  }
+}
+
 bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 }  // namespace
@@ -381,6 +544,13 @@ int sk_attn_fwd_mfma(const AttnParams& p, hipStream_t stream) {
 }
 
 int sk_attn_bwd_mfma(const AttnParams& p, hipStream_t stream) {
+  if (p.Lq <= OT && p.Lk <= OT && p.dk <= 64) {  // single tile on both sides: one fused launch (4 tiles of LDS)
+    dim3 grid(1, p.H, p.B);
+    if (p.dk == 32) hipLaunchKernelGGL(attn_bwd_fused_mfma_kernel<32>, grid, dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL(attn_bwd_fused_mfma_kernel<64>, grid, dim3(256), 0, stream, p);
+    SK_CHECK_LAUNCH("skhip_attn_bwd(mfma, fused)");
+    return SK_OK;
+  }
   dim3 gq((p.Lq + 63) / 64, p.H, p.B), gk((p.Lk + 63) / 64, p.H, p.B);
   if (p.dk == 32) {
     hipLaunchKernelGGL(attn_bwd_dq_mfma_kernel<32>, gq, dim3(256), 0, stream, p);

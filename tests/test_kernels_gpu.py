@@ -204,14 +204,15 @@ def test_attention(L, dtype, case):
             assert rel_err(got, ref) <= t
 
 
-def test_attention_mfma_dropout_matches_valu(L):
+@pytest.mark.parametrize("Lq,Lk", [(70, 90), (40, 52)])  # two-launch backward / fused single-tile backward
+def test_attention_mfma_dropout_matches_valu(L, Lq, Lk):
     """Same seed -> the MFMA and the vector-ALU kernels drop the same probabilities, forward and backward."""
     import os
     g = torch.Generator().manual_seed(5)
-    B, H, Lq, Lk, d = 3, 4, 70, 90, 64
+    B, H, d = 3, 4, 64
     dt = torch.bfloat16
     q, k, v = rnd((B, Lq, H, d), dt, g), rnd((B, Lk, H, d), dt, g), rnd((B, Lk, H, d), dt, g)
-    lens = torch.tensor([Lk, 50, 77])
+    lens = torch.tensor([Lk, Lk // 2 + 5, Lk - 13])
     keypad = torch.arange(Lk)[None, :] >= lens[:, None]
     do = rnd((B, Lq, H, d), dt, g)
     res = {}

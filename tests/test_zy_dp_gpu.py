@@ -1,7 +1,10 @@
 """Data-parallel training step on the GPU path with two ranks (both on cuda:0, gloo transport so
 that one card suffices): every rank runs the padding-free forward / backward on its shard of the
 golden batch with the bucketed gradient reducer hooked into backward; the summed gradients must
-equal the reference's full-batch gradients (the loss is a token SUM)."""
+equal the reference's full-batch gradients (the loss is a token SUM).
+
+The file name sorts late on purpose: a multi-process test is the likeliest to be disturbed by the
+machine, and `pytest -x` should not lose the single-process tests behind it."""
 import os
 import socket
 import sys
@@ -25,12 +28,15 @@ def _free_port():
 def _worker(rank, world, port, out, packed):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import faulthandler
+    faulthandler.dump_traceback_later(75, exit=True)  # a stuck rank reports where, then fails the test
     import torch.distributed as dist
     from specialk_amd import ops
     from specialk_amd.parallel import GradBucketReducer, all_reduce_scalars
     from test_model_gpu import build_tiny, load_sd, t
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import datetime
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
     torch.cuda.set_device(0)
     g = load_golden("transformer_untied")
     m = load_sd(build_tiny(g, False), split_prefixed(g, "w:")).eval()
@@ -61,7 +67,8 @@ def _worker(rank, world, port, out, packed):
 @pytest.mark.parametrize("packed", [True, False])
 def test_two_rank_step_matches_full_batch_gradients(tmp_path, packed):
     out = str(tmp_path / "dp.pt")
-    mp.spawn(_worker, args=(2, _free_port(), out, packed), nprocs=2, join=True)
+    # ranks are forked from the clean fork server started in conftest.py (see there)
+    mp.start_processes(_worker, args=(2, _free_port(), out, packed), nprocs=2, join=True, start_method="forkserver")
     got = torch.load(out)
     g = load_golden("transformer_untied")
     assert abs(float(got["stats"][0]) - float(g["loss_ls"])) <= 1e-5 * float(g["loss_ls"])
