@@ -525,7 +525,7 @@ __global__ __launch_bounds__(256, 3) void gemm_kernel(GemmParams p) {
 }  // namespace b16g
 
 // ============================================================================ bf16, 256x256 tile
-// Large-tile variant of the direct-to-LDS kernel for K-contiguous operands (NT).  A 128x128
+// Large-tile variant of the direct-to-LDS kernel (all three operand layouts).  A 128x128
 // tile needs 64 B of operand fill per clock per CU at full MFMA rate, which is all the
 // global -> LDS path delivers; a 256x256 tile halves that.  It pays when there are many more
 // tiles than CUs (the generator projection); with about one tile per CU the 128x128 kernels'
@@ -555,11 +555,76 @@ constexpr int OPER_BYTES = 256 * BK * 2;         // 16384
 constexpr int STAGE_BYTES = 2 * OPER_BYTES;      // A + B
 constexpr int SMEM_BYTES = STAGES * STAGE_BYTES;  // 128 KiB
 
-using b16g::Loader;
+using b16::key_t;
+using b16g::g_zero_page;
+using b16g::gbl_ptr_t;
 using b16g::key_ka;
 using b16g::key_kb;
+using b16g::lds_ptr_t;
 
-template <typename TOut>
+// Row-contiguous ("T") operand image of a 256-wide tile: [32 k][256 rows], 512-byte k-rows whose
+// sixteen 32-byte segments are XOR-swizzled (low three bits) with key_t(k), so that the transposing
+// ds_read_b64_tr_b16 fragment reads (eight k-rows x 32 bytes per 32-lane half) spread over all banks.
+__device__ __forceinline__ int t_off256(int k, int col) {
+  return k * 512 + ((((col >> 4) ^ key_t(k)) & 15) << 5) + (col & 15) * 2;
+}
+
+// This lane's two direct-to-LDS loads per operand tile.  K-contiguous operand: instruction idx covers
+// rows 16*idx..+15 (64-byte rows, chunk swizzle on the source address, as in the 128-tile kernel);
+// T operand: instruction idx covers k-rows 2*idx, 2*idx+1 (32 sixteen-byte pieces each).
+template <bool T_LAYOUT, bool IS_B>
+struct Loader {
+  const char* ptr[2];
+  int64_t step;
+  int kofs[2];
+  bool rows_ok[2];
+  __device__ __forceinline__ void init(const bf16_t* base, int64_t ld, int r0, int R, int kbeg, int wave, int lane) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int idx = wave * 2 + j;
+      if (T_LAYOUT) {
+        const int k = 2 * idx + (lane >> 5), pos = lane & 31;
+        const int col = (((pos >> 1) ^ key_t(k)) & 15) * 16 + (pos & 1) * 8;
+        kofs[j] = k;
+        rows_ok[j] = r0 + col + 8 <= R;
+        ptr[j] = (const char*)(base + (int64_t)(kbeg + k) * ld + r0 + col);
+        step = (int64_t)BK * ld * 2;
+      } else {
+        const int row = 16 * idx + (lane >> 2), cpos = lane & 3;
+        const int c = cpos ^ (IS_B ? key_kb(row) : key_ka(row));
+        kofs[j] = 8 * c;
+        rows_ok[j] = true;
+        ptr[j] = (const char*)(base + (int64_t)min(r0 + row, R - 1) * ld + kbeg + 8 * c);
+        step = BK * 2;
+      }
+    }
+  }
+  __device__ __forceinline__ void issue(char* lds, int wave_u, int k0, int kend) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const bool ok = T_LAYOUT ? (rows_ok[j] && k0 + kofs[j] < kend) : (k0 + kofs[j] + 8 <= kend);
+      const char* src = ok ? ptr[j] : (const char*)g_zero_page;
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(lds + (wave_u * 2 + j) * 1024), 16, 0, 0);
+      ptr[j] += step;
+    }
+  }
+};
+
+// One MFMA operand fragment (8 bf16 per lane) from an operand image at per-lane byte offset `off`.
+template <bool T_LAYOUT>
+__device__ __forceinline__ bf16x8_t read_frag(const char* image, int off) {
+  if (T_LAYOUT) {
+    typedef __attribute__((address_space(3))) s16x4_t* lds_v4;
+    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(image + off));
+    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(image + off + 4 * 512));  // k + 4: same key
+    const s16x8_t f = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8_t, f);
+  } else {
+    return *(const bf16x8_t*)(image + off);
+  }
+}
+
+template <bool A_T, bool B_T, typename TOut>
 __global__ __launch_bounds__(512, 1) void gemm_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -573,8 +638,8 @@ __global__ __launch_bounds__(512, 1) void gemm_kernel(GemmParams p) {
   const int kend = min(p.K, kbeg + p.k_per_split);
   const int nk = (kend - kbeg + BK - 1) / BK;
 
-  Loader<false, false> la;
-  Loader<false, true> lb;
+  Loader<A_T, false> la;
+  Loader<B_T, true> lb;
   la.init((const bf16_t*)p.A, p.lda, m0, p.M, kbeg, wave, lane);
   lb.init((const bf16_t*)p.B, p.ldb, n0, p.N, kbeg, wave, lane);
 
@@ -600,16 +665,26 @@ __global__ __launch_bounds__(512, 1) void gemm_kernel(GemmParams p) {
 
   // per-lane fragment offsets inside a stage
   int offa[8], offb[4];
+  {
+    const int l15 = lane & 15, g = lane >> 4;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int row = wrow + i * 16 + (lane & 15);
-    offa[i] = row * 64 + (((lane >> 4) ^ key_ka(row)) << 4);
-  }
+    for (int i = 0; i < 8; ++i) {
+      if (A_T) {
+        offa[i] = t_off256(8 * g + (l15 >> 2), wrow + 16 * i + 4 * (l15 & 3));
+      } else {
+        const int row = wrow + i * 16 + l15;
+        offa[i] = row * 64 + ((g ^ key_ka(row)) << 4);
+      }
+    }
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int rho = lane & 15;
-    const int row = wcol + 16 * (rho >> 2) + 4 * i + (rho & 3);
-    offb[i] = OPER_BYTES + row * 64 + (((lane >> 4) ^ key_kb(row)) << 4);
+    for (int i = 0; i < 4; ++i) {
+      if (B_T) {  // standard column order (see write_tile, PERM = false)
+        offb[i] = OPER_BYTES + t_off256(8 * g + (l15 >> 2), wcol + 16 * i + 4 * (l15 & 3));
+      } else {    // permuted rows: a lane ends up with 16 consecutive output columns
+        const int row = wcol + 16 * (l15 >> 2) + 4 * i + (l15 & 3);
+        offb[i] = OPER_BYTES + row * 64 + ((g ^ key_kb(row)) << 4);
+      }
+    }
   }
 
   int cs = 0, is = 3;  // stage being computed / stage being filled
@@ -620,9 +695,9 @@ __global__ __launch_bounds__(512, 1) void gemm_kernel(GemmParams p) {
     const char* st = smem + cs * STAGE_BYTES;
     bf16x8_t fb[4], fa[8];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) fb[i] = *(const bf16x8_t*)(st + offb[i]);
+    for (int i = 0; i < 4; ++i) fb[i] = read_frag<B_T>(st, offb[i]);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) fa[i] = *(const bf16x8_t*)(st + offa[i]);
+    for (int i = 0; i < 8; ++i) fa[i] = read_frag<A_T>(st, offa[i]);
     if (kt + 3 < nk) issue(is, kt + 3);
     // ---- M: tile kt+1 landed (this wave's part), own LDS reads done, then multiply
     if (kt + 3 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
@@ -645,8 +720,8 @@ __global__ __launch_bounds__(512, 1) void gemm_kernel(GemmParams p) {
   }
   if (wave < 4) __builtin_amdgcn_s_barrier();  // balances the upper half's extra barrier
 
-  write_tile<TOut, bf16_t, true>(p, acc, m0 + wrow, n0 + wcol, lane);
-  write_tile<TOut, bf16_t, true>(p, acc + 4, m0 + wrow + 64, n0 + wcol, lane);
+  write_tile<TOut, bf16_t, !B_T>(p, acc, m0 + wrow, n0 + wcol, lane);
+  write_tile<TOut, bf16_t, !B_T>(p, acc + 4, m0 + wrow + 64, n0 + wcol, lane);
 }
 }  // namespace b16x
 
@@ -936,8 +1011,13 @@ extern "C" int skhip_gemm(int layout, const void* A, const void* B, void* C, con
     const double fill = (double)t256 / (double)(rounds * ncu);
     use_big = t256 >= 8 * ncu || (K >= 1024 && fill >= 0.7) || (rounds == 1 && fill >= 0.7);
   }
+  // Weight gradients (TN, long K, split-K): the 256-tile kernel when the output has enough 256-tiles
+  // to keep the split count, and with it the slab traffic, moderate (measured at K = 25k: 2048x512
+  // 81 vs 98 us, 1536x512 66 vs 72, 35000x512 1365 vs 1461; 1024x512 and 512x512 are slower).
+  if (in_dtype == SK_BF16 && fast && layout == SK_GEMM_TN && workspace && K >= 4096)
+    use_big = ((M + 255) / 256) * ((N + 255) / 256) >= 12;
   if (env_big && env_big[0] == '0') use_big = false;
-  if (env_big && env_big[0] == '1') use_big = in_dtype == SK_BF16 && fast && layout == SK_GEMM_NT;
+  if (env_big && env_big[0] == '1') use_big = in_dtype == SK_BF16 && fast;
   if (use_big) {
     p.tiles_m = (int)((M + b16x::XM - 1) / b16x::XM);
     p.tiles_n = (int)((N + b16x::XN - 1) / b16x::XN);
@@ -976,14 +1056,22 @@ extern "C" int skhip_gemm(int layout, const void* A, const void* B, void* C, con
   (fast ? launch_gemm(f32::gemm_kernel<AT, BT, true>, grid, f32::SMEM_BYTES, stream, p)                     \
         : launch_gemm(f32::gemm_kernel<AT, BT, false>, grid, f32::SMEM_BYTES, stream, p))
   if (use_big) {
-    int rc;
+#define LAUNCH_BIG(AT, BT, TO)                                                                          \
+  do {                                                                                                  \
+    int rc = sk_allow_big_lds(b16x::gemm_kernel<AT, BT, TO>, b16x::SMEM_BYTES);                         \
+    if (rc) return rc;                                                                                  \
+    hipLaunchKernelGGL((b16x::gemm_kernel<AT, BT, TO>), grid, dim3(512), b16x::SMEM_BYTES, stream, p);  \
+  } while (0)
     if (out_dtype == SK_BF16) {
-      if ((rc = sk_allow_big_lds(b16x::gemm_kernel<bf16_t>, b16x::SMEM_BYTES))) return rc;
-      hipLaunchKernelGGL(b16x::gemm_kernel<bf16_t>, grid, dim3(512), b16x::SMEM_BYTES, stream, p);
+      if (layout == SK_GEMM_NT) LAUNCH_BIG(false, false, bf16_t);
+      else if (layout == SK_GEMM_NN) LAUNCH_BIG(false, true, bf16_t);
+      else LAUNCH_BIG(true, true, bf16_t);
     } else {
-      if ((rc = sk_allow_big_lds(b16x::gemm_kernel<float>, b16x::SMEM_BYTES))) return rc;
-      hipLaunchKernelGGL(b16x::gemm_kernel<float>, grid, dim3(512), b16x::SMEM_BYTES, stream, p);
+      if (layout == SK_GEMM_NT) LAUNCH_BIG(false, false, float);
+      else if (layout == SK_GEMM_NN) LAUNCH_BIG(false, true, float);
+      else LAUNCH_BIG(true, true, float);
     }
+#undef LAUNCH_BIG
   } else if (in_dtype == SK_BF16) {
     if (out_dtype == SK_BF16) {
       if (layout == SK_GEMM_NT) LAUNCH_B16(false, false, bf16_t);

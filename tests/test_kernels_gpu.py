@@ -104,6 +104,16 @@ def test_gemm_bf16_kernel_variants(L, env):
             assert rel_err(out, ref) <= BF16_RTOL, (env, M, N, K)
             out32 = L.gemm(L.GEMM_NT, A.to(DEV), B.to(DEV), M, N, K, K, K, out_dtype=torch.float32, split_k=False)
             assert rel_err(out32, A.double() @ B.double().t()) <= 1e-5, (env, M, N, K)
+        # row-contiguous operands (input-gradient NN and weight-gradient TN forms), with and without split-K
+        for (M, N, K) in [(256, 256, 64), (520, 264, 1096), (1000, 72, 40), (8, 512, 3000)]:
+            A, B = rnd((K, M), torch.bfloat16, g), rnd((K, N), torch.bfloat16, g)
+            ref = A.double().t() @ B.double()
+            for split in (False, True):
+                out = L.gemm(L.GEMM_TN, A.to(DEV), B.to(DEV), M, N, K, M, N, out_dtype=torch.float32, split_k=split)
+                assert rel_err(out, ref) <= 1e-5, (env, "TN", M, N, K, split)
+            An = A.t().contiguous()
+            out = L.gemm(L.GEMM_NN, An.to(DEV), B.to(DEV), M, N, K, K, N, split_k=False)
+            assert rel_err(out, ref) <= BF16_RTOL, (env, "NN", M, N, K)
     finally:
         for k, v in old.items():
             os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)

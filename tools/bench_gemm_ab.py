@@ -10,7 +10,11 @@ from specialk_amd import _lib as L
 T, d, F, V = 33280, 512, 2048, 35000
 P = 25472
 SHAPES = [
-    ("sq NT 8192^3", 0, 8192, 8192, 8192, torch.bfloat16),
+    ("ffnw TN 2048x512xP", 2, F, d, P, torch.float32),
+    ("ffnw TN 512x2048xP", 2, d, F, P, torch.float32),
+    ("qkvw TN 1536x512xP", 2, 3 * d, d, P, torch.float32),
+    ("kvw TN 1024x512xP", 2, 2 * d, d, P, torch.float32),
+    ("ow TN 512x512xP", 2, d, d, P, torch.float32),
     ("gen NT Px35000x512", 0, P, V, d, torch.bfloat16),
     ("gendx NT Px512x35000", 0, P, d, V, torch.bfloat16),
     ("genw TN 35000x512xP", 2, V, d, P, torch.float32),
