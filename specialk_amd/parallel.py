@@ -42,7 +42,11 @@ class GradBucketReducer:
         self._pending = {}
         self._handles = []
         self._hooks = []
-        if self.world > 1:
+        # A transport that cannot read device memory (gloo) gets the buckets through a host copy at
+        # finish(); in-backward overlap is only for RCCL, which reduces the device buffers in place.
+        self._staged = (self.world > 1 and self.buckets and self.buckets[0][0].is_cuda
+                        and dist.get_backend(process_group) != "nccl")
+        if self.world > 1 and not self._staged:
             for bi, (_, plist) in enumerate(self.buckets):
                 for p in plist:
                     self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(bi)))
@@ -85,7 +89,13 @@ class GradBucketReducer:
     def finish(self):
         """Wait for every bucket's all-reduce; buckets whose parameters got no gradient this
         step (unused parameters) are reduced here so that all ranks stay in lock-step."""
-        if self.world > 1:
+        if self._staged:
+            for bi, (flat, _) in enumerate(self.buckets):
+                host = flat.cpu()
+                dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
+                flat.copy_(host)
+                self._pending[bi] = 0
+        elif self.world > 1:
             for bi, (flat, _) in enumerate(self.buckets):
                 if self._pending[bi] > 0:
                     self._handles.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
@@ -97,7 +107,11 @@ class GradBucketReducer:
 
 def all_reduce_scalars(values, device):
     """Sum a few python/torch scalars over ranks in one collective (loss, n_word, n_correct)."""
-    t = torch.as_tensor(values, dtype=torch.float64, device=device)
     if dist.is_initialized() and dist.get_world_size() > 1:
+        if dist.get_backend() == "nccl":  # only RCCL reads device memory
+            t = torch.as_tensor(values, dtype=torch.float64, device=device)
+        else:
+            t = torch.as_tensor([float(v) for v in values], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
-    return t
+        return t.to(device)
+    return torch.as_tensor(values, dtype=torch.float64, device=device)

@@ -1,5 +1,5 @@
 """Data-parallel training step on the GPU path with two ranks (both on cuda:0, gloo transport so
-that one card suffices): every rank runs the padding-free forward / backward on its shard of the
+that one card suffices; the reducer hands gloo host copies of its device buckets): every rank runs the padding-free forward / backward on its shard of the
 golden batch with the bucketed gradient reducer hooked into backward; the summed gradients must
 equal the reference's full-batch gradients (the loss is a token SUM).
 
@@ -29,14 +29,14 @@ def _worker(rank, world, port, out, packed):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import faulthandler
-    faulthandler.dump_traceback_later(75, exit=True)  # a stuck rank reports where, then fails the test
+    faulthandler.dump_traceback_later(40, exit=True)  # a stuck rank reports where, then fails the test
     import torch.distributed as dist
     from specialk_amd import ops
     from specialk_amd.parallel import GradBucketReducer, all_reduce_scalars
     from test_model_gpu import build_tiny, load_sd, t
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     import datetime
-    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=90))
     torch.cuda.set_device(0)
     g = load_golden("transformer_untied")
     m = load_sd(build_tiny(g, False), split_prefixed(g, "w:")).eval()
