@@ -77,6 +77,7 @@ def build(cfg, dtype, device):
     return m, opt
 
 
+BATCHED_WGRADS = os.environ.get("SK_BENCH_BATCHED_WGRADS", "1") != "0"
 PACKED = True  # run the network on the batch without its padding rows (--padded turns it off)
 
 
@@ -93,7 +94,11 @@ def train_step(m, opt, batch, reducer):
     else:
         pred = m(src_seq, src_pos, tgt_seq, tgt_pos)
         loss, stats = ops.xent(pred.view(-1, pred.size(2)), tgt_seq[:, 1:], True, unit_grad=True)
-    loss.backward()
+    if BATCHED_WGRADS:  # as TransformerModel.compute_epoch does
+        with ops.batched_weight_grads(on_ready=reducer.mark_ready if reducer is not None else None):
+            loss.backward()
+    else:
+        loss.backward()
     if reducer is not None:
         reducer.finish()
     opt.step_and_update_lr()
@@ -103,7 +108,7 @@ def train_step(m, opt, batch, reducer):
 def gemm_roofline(m, opt, batch, steps):
     """Instrumented extra steps (after the timed region, same process, same data): every bf16
     GEMM launch is bracketed by HIP events on the launch stream.  Algorithmic FLOPs credit only
-    non-pad rows (padding work earns no credit)."""
+    non-pad rows: padding work earns no credit."""
     from specialk_amd import _lib as L
     src_seq, _, tgt_seq, _ = batch
     Ts, Tt = src_seq.numel(), tgt_seq[:, :-1].numel()
@@ -122,19 +127,29 @@ def gemm_roofline(m, opt, batch, steps):
         records.append((e0, e1, 2.0 * M * N * K * f, A.dtype))
         return out
 
-    L.gemm = timed
+    orig_grouped = L.gemm_grouped_tn
+
+    def timed_grouped(problems):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        orig_grouped(problems)
+        e1.record()
+        fl = sum(2.0 * M * N * K * frac.get(K, 1.0) for _, _, _, M, N, K, *_ in problems)
+        records.append((e0, e1, fl, problems[0][0].dtype))
+
+    L.gemm, L.gemm_grouped_tn = timed, timed_grouped
     try:
         for _ in range(steps):
             train_step(m, opt, batch, None)
         torch.cuda.synchronize()
     finally:
-        L.gemm = orig
+        L.gemm, L.gemm_grouped_tn = orig, orig_grouped
     ms = sum(e0.elapsed_time(e1) for e0, e1, _, _ in records)
     flops = sum(f for _, _, f, _ in records)
     n = len(records)
     return dict(bound="mfma", achieved=round(flops / (ms * 1e-3) / 1e12, 2), peak=MFMA_BF16_PEAK_TFLOPS,
                 unit="TFLOP/s", frac=round(flops / (ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4), traffic=None,
-                kernel="b16g/b16/b16x::gemm_kernel (bf16 MFMA GEMMs, all layouts)", launches_per_step=n // steps,
+                kernel="b16x/b16g/b16::gemm_kernel + b16x::gemm_grouped_tn_kernel (bf16 MFMA GEMMs, all layouts)", launches_per_step=n // steps,
                 avg_launch_us=round(ms * 1e3 / n, 2), avg_algorithmic_gflop_per_launch=round(flops / n / 1e9, 3))
 
 

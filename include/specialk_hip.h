@@ -66,6 +66,16 @@ int skhip_gemm(int layout, const void* A, const void* B, void* C, const void* bi
                float alpha, int epilogue, int in_dtype, int out_dtype,
                void* workspace, int64_t workspace_bytes, void* stream);
 
+/* Grouped weight gradients: n independent products  C_i (+)= A_i^T B_i  in one pass over the chip —
+ * the autograd backward of every nn.Linear / Conv1d(k=1) weight of the layers (SubLayers.py:46-48,62,
+ * 73-74), which the reference's autograd engine runs as one small GEMM per weight.  A_i (K_i x M_i,
+ * row stride lda_i) and B_i (K_i x N_i, ldb_i) are bf16 with rows contiguous, C_i (M_i x N_i, ldc_i) is
+ * fp32.  problems: HOST array of n x 10 int64 {A, B, C, M, N, K, lda, ldb, ldc, accumulate}; operand
+ * addresses, M, N, lda, ldb must be multiples of 16 bytes / 8 elements.  workspace: fp32 scratch for the
+ * K-split slabs of the tiles that do not fill a whole round of the chip (NULL: no split).
+ * Deterministic (fixed summation order).                                                     */
+int skhip_gemm_grouped_tn(const int64_t* problems, int n, void* workspace, int64_t workspace_bytes, void* stream);
+
 /* Column sums: out[n] (+)= sum_m X[m][n]  (bias gradients, the autograd backward of the
  * `+ bias` in nn.Linear, SubLayers.py:46-48,62).  out is fp32.  workspace: optional fp32
  * scratch (>= 64*N floats lets the rows be summed in parallel chunks, combined in a fixed

@@ -19,7 +19,7 @@ LIB_PATH = os.path.join(_HERE, "libspecialk_hip.so")
 
 # every symbol include/specialk_hip.h declares
 EXPORTS = [
-    "skhip_version", "skhip_last_error", "skhip_init", "skhip_gemm", "skhip_colsum", "skhip_attn_fwd",
+    "skhip_version", "skhip_last_error", "skhip_init", "skhip_gemm", "skhip_gemm_grouped_tn", "skhip_colsum", "skhip_attn_fwd",
     "skhip_attn_bwd", "skhip_attn_varlen_fwd", "skhip_attn_varlen_bwd", "skhip_add_ln_fwd", "skhip_add_ln_bwd_ws_floats", "skhip_add_ln_bwd", "skhip_embed_fwd",
     "skhip_embed_bwd", "skhip_xent_fwd_bwd", "skhip_adam_multi", "skhip_cast_multi", "skhip_cast2d_multi", "skhip_convert",
     "skhip_decode_attn", "skhip_beam_topk_ws_bytes", "skhip_beam_topk", "skhip_gather_rows",
@@ -46,6 +46,7 @@ def load():
     lib.skhip_add_ln_bwd_ws_floats.argtypes = [c_int]
     lib.skhip_beam_topk_ws_bytes.restype = c_i64
     lib.skhip_beam_topk_ws_bytes.argtypes = [c_int, c_int, c_i64]
+    lib.skhip_gemm_grouped_tn.argtypes = [ctypes.POINTER(c_i64), c_int, c_p, c_i64, c_p]
     lib.skhip_gemm.argtypes = [c_int, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_f32,
                                c_int, c_int, c_int, c_p, c_i64, c_p]
     lib.skhip_colsum.argtypes = [c_p, c_p, c_i64, c_i64, c_i64, c_int, c_int, c_p, c_i64, c_p]
@@ -134,6 +135,21 @@ def gemm(layout, A, B, M, N, K, lda, ldb, out=None, ldc=None, bias=None, aux=Non
                         ws.numel() if ws is not None else 0, _stream())
     _check(rc, "skhip_gemm")
     return out
+
+
+def gemm_grouped_tn(problems):
+    """problems: list of (A, B, C, M, N, K, lda, ldb, ldc, accumulate) with A (K, M) and B (K, N) bf16 views
+    (rows contiguous), C (M, N) fp32: C (+)= A^T B for all of them in one pass over the chip."""
+    lib = load()
+    n = len(problems)
+    if n == 0:
+        return
+    table = (c_i64 * (10 * n))()
+    for i, (A, B, C, M, N, K, lda, ldb, ldc, acc) in enumerate(problems):
+        assert A.dtype == torch.bfloat16 and B.dtype == torch.bfloat16 and C.dtype == torch.float32
+        table[10 * i:10 * i + 10] = [A.data_ptr(), B.data_ptr(), C.data_ptr(), M, N, K, lda, ldb, ldc, int(bool(acc))]
+    ws = workspace(192 << 20)  # up to two rounds of 256 CUs x 256 KB tile slabs, with room to spare
+    _check(lib.skhip_gemm_grouped_tn(table, n, _ptr(ws), ws.numel(), _stream()), "skhip_gemm_grouped_tn")
 
 
 def colsum(X, M, N, ldx, out=None, accumulate=False):

@@ -32,6 +32,8 @@
 // and out-of-range 8-element chunks are zero-filled by one predicate per chunk.  Anything
 // else runs the GENERIC instantiation with element-wise guards.
 #include "common.h"
+#include <algorithm>
+#include <vector>
 #include <stdlib.h>
 
 namespace {
@@ -137,11 +139,11 @@ __device__ __forceinline__ void store_cols(T* dst, const float (&v)[NC]) {
 
 // NC consecutive columns of one output row, held by one lane.
 template <typename TOut, typename TIn, int NC>
-__device__ __forceinline__ void write_cols(const GemmParams& p, float (&v)[NC], int row, int col) {
+__device__ __forceinline__ void write_cols(const GemmParams& p, float (&v)[NC], int row, int col, int slab) {
   if (col >= p.N) return;
   const bool full = col + NC <= p.N;
-  if (gridDim.z > 1) {  // split-K: raw partial sums to the slab of this split
-    float* w = p.ws + ((int64_t)blockIdx.z * p.M + row) * p.N + col;
+  if (slab >= 0) {  // split-K: raw partial sums to the slab of this split
+    float* w = p.ws + ((int64_t)slab * p.M + row) * p.N + col;
     if (full && (p.N & 3) == 0) store_cols<float, NC>(w, v);
     else
       for (int j = 0; j < NC; ++j) if (col + j < p.N) w[j] = v[j];
@@ -179,10 +181,14 @@ __device__ __forceinline__ void write_cols(const GemmParams& p, float (&v)[NC], 
   store_cols<TOut, NC>((TOut*)p.C + off, v);
 }
 
+// Slab index of this block's partial sums under split-K over gridDim.z, -1 without a split.
+__device__ __forceinline__ int grid_slab() { return gridDim.z > 1 ? (int)blockIdx.z : -1; }
+
 // acc[mi][ni] holds C^T tiles: lane l owns output row 16*mi + (l & 15); register r of tile ni
 // is output column  PERM ? 16*(l>>4) + 4*ni + r  :  16*ni + 4*(l>>4) + r   (wave-local).
 template <typename TOut, typename TIn, bool PERM>
-__device__ __forceinline__ void write_tile(const GemmParams& p, const f32x4_t (*acc)[4], int row0, int col0, int lane) {
+__device__ __forceinline__ void write_tile(const GemmParams& p, const f32x4_t (*acc)[4], int row0, int col0, int lane,
+                                           int slab) {
   const int g = lane >> 4;
 #pragma unroll
   for (int mi = 0; mi < 4; ++mi) {
@@ -194,12 +200,12 @@ __device__ __forceinline__ void write_tile(const GemmParams& p, const f32x4_t (*
       for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[ni * 4 + r] = acc[mi][ni][r];
-      write_cols<TOut, TIn, 16>(p, v, row, col0 + 16 * g);
+      write_cols<TOut, TIn, 16>(p, v, row, col0 + 16 * g, slab);
     } else {
 #pragma unroll
       for (int ni = 0; ni < 4; ++ni) {
         float v[4] = {acc[mi][ni][0], acc[mi][ni][1], acc[mi][ni][2], acc[mi][ni][3]};
-        write_cols<TOut, TIn, 4>(p, v, row, col0 + 16 * ni + 4 * g);
+        write_cols<TOut, TIn, 4>(p, v, row, col0 + 16 * ni + 4 * g, slab);
       }
     }
   }
@@ -365,7 +371,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
     }
     __syncthreads();
   }
-  write_tile<TOut, bf16_t, !B_T>(p, acc, m0 + wrow, n0 + wcol, lane);
+  write_tile<TOut, bf16_t, !B_T>(p, acc, m0 + wrow, n0 + wcol, lane, grid_slab());
 }
 }  // namespace b16
 
@@ -520,7 +526,7 @@ __global__ __launch_bounds__(256, 3) void gemm_kernel(GemmParams p) {
     cs = cs == STAGES - 1 ? 0 : cs + 1;
     is = is == STAGES - 1 ? 0 : is + 1;
   }
-  write_tile<TOut, bf16_t, !B_T>(p, acc, m0 + wrow, n0 + wcol, lane);
+  write_tile<TOut, bf16_t, !B_T>(p, acc, m0 + wrow, n0 + wcol, lane, grid_slab());
 }
 }  // namespace b16g
 
@@ -624,18 +630,15 @@ __device__ __forceinline__ bf16x8_t read_frag(const char* image, int off) {
   }
 }
 
+// One 256 x 256 output tile over K range [kbeg, kend): the whole block's work.  slab >= 0 sends the
+// raw partial sums to that split-K slab instead of the epilogue.
 template <bool A_T, bool B_T, typename TOut>
-__global__ __launch_bounds__(512, 1) void gemm_kernel(GemmParams p) {
+__device__ __forceinline__ void gemm_tile(const GemmParams& p, int tile_m, int tile_n, int kbeg, int kend, int slab) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  int tile_m, tile_n;
-  tile_of(p, blockIdx.x, tile_m, tile_n);
   const int m0 = tile_m * XM, n0 = tile_n * XN;
   const int wrow = (wave >> 2) * 128, wcol = (wave & 3) * 64;
-
-  const int kbeg = blockIdx.z * p.k_per_split;
-  const int kend = min(p.K, kbeg + p.k_per_split);
   const int nk = (kend - kbeg + BK - 1) / BK;
 
   Loader<A_T, false> la;
@@ -720,8 +723,93 @@ __global__ __launch_bounds__(512, 1) void gemm_kernel(GemmParams p) {
   }
   if (wave < 4) __builtin_amdgcn_s_barrier();  // balances the upper half's extra barrier
 
-  write_tile<TOut, bf16_t, !B_T>(p, acc, m0 + wrow, n0 + wcol, lane);
-  write_tile<TOut, bf16_t, !B_T>(p, acc + 4, m0 + wrow + 64, n0 + wcol, lane);
+  write_tile<TOut, bf16_t, !B_T>(p, acc, m0 + wrow, n0 + wcol, lane, slab);
+  write_tile<TOut, bf16_t, !B_T>(p, acc + 4, m0 + wrow + 64, n0 + wcol, lane, slab);
+}
+
+template <bool A_T, bool B_T, typename TOut>
+__global__ __launch_bounds__(512, 1) void gemm_kernel(GemmParams p) {
+  int tile_m, tile_n;
+  tile_of(p, blockIdx.x, tile_m, tile_n);
+  const int kbeg = blockIdx.z * p.k_per_split;
+  gemm_tile<A_T, B_T, TOut>(p, tile_m, tile_n, kbeg, min(p.K, kbeg + p.k_per_split), grid_slab());
+}
+
+// ---- grouped weight gradients: many independent C_i (M_i x N_i, fp32) (+)= A_i^T B_i products with
+// row-contiguous bf16 operands (A_i is K_i x M_i, B_i is K_i x N_i) in ONE launch.  Every block
+// computes one 256-tile of one problem (optionally one K split of it); the problem table travels in
+// the kernel arguments.  Small outputs (a 512 x 512 weight is four tiles) then share the chip with
+// the others instead of each being cut into dozens of K splits with their slab traffic.
+struct GroupDesc {
+  const void* A;
+  const void* B;
+  float* C;
+  float* ws;         // slabs [splits][M][N] when splits > 1
+  int M, N, K;
+  int lda, ldb, ldc;
+  int first_block;   // blocks of the problems before this one
+  int splits, kps;   // K splits and K per split
+  int flags;         // bit 0: accumulate into C, bit 1: C allows 16-byte access
+};
+constexpr int MAX_GROUP = 48;
+struct GroupArgs {
+  int n, pad;
+  GroupDesc d[MAX_GROUP];
+};
+static_assert(sizeof(GroupArgs) <= 4096, "kernel arguments are limited to 4 KB");
+
+__device__ __forceinline__ GemmParams params_of(const GroupDesc& d) {
+  GemmParams p;
+  p.A = d.A; p.B = d.B; p.C = d.C; p.bias = nullptr; p.aux = nullptr; p.ws = d.ws;
+  p.lda = d.lda; p.ldb = d.ldb; p.ldc = d.ldc;
+  p.M = d.M; p.N = d.N; p.K = d.K;
+  p.k_per_split = d.kps;
+  p.tiles_m = (d.M + XM - 1) / XM;
+  p.tiles_n = (d.N + XN - 1) / XN;
+  p.epi = (d.flags & 1) ? SK_EPI_ACCUM : 0;
+  p.vec_c = (d.flags >> 1) & 1;
+  p.alpha = 1.f;
+  p.group = 1;
+  return p;
+}
+
+__global__ __launch_bounds__(512, 1) void gemm_grouped_tn_kernel(GroupArgs g) {
+  const int bid = blockIdx.x;
+  int i = 0;
+  while (i + 1 < g.n && g.d[i + 1].first_block <= bid) ++i;  // uniform: a few scalar loads
+  const GemmParams p = params_of(g.d[i]);
+  const int local = bid - g.d[i].first_block, tiles = p.tiles_m * p.tiles_n;
+  const int split = local / tiles, tile = local - split * tiles;
+  const int kbeg = split * p.k_per_split;
+  gemm_tile<true, true, float>(p, tile / p.tiles_n, tile % p.tiles_n, kbeg, min(p.K, kbeg + p.k_per_split),
+                               g.d[i].splits > 1 ? split : -1);
+}
+
+// Adds the K-split slabs of the split problems of a group (blockIdx.y = problem) in split order.
+__global__ __launch_bounds__(256) void grouped_reduce_kernel(GroupArgs g) {
+  const GroupDesc& d = g.d[blockIdx.y];
+  if (d.splits <= 1) return;
+  const int64_t total = (int64_t)d.M * d.N;
+  const bool acc = d.flags & 1;
+  if ((d.N & 3) == 0 && (d.flags & 2)) {
+    for (int64_t i = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) * 4; i < total; i += (int64_t)gridDim.x * blockDim.x * 4) {
+      float4 s = *(const float4*)(d.ws + i);
+      for (int z = 1; z < d.splits; ++z) {
+        const float4 v = *(const float4*)(d.ws + (int64_t)z * total + i);
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+      }
+      float* c = d.C + (i / d.N) * d.ldc + (i % d.N);
+      if (acc) { const float4 o = *(const float4*)c; s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w; }
+      *(float4*)c = s;
+    }
+  } else {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+      float s = 0.f;
+      for (int z = 0; z < d.splits; ++z) s += d.ws[(int64_t)z * total + i];
+      float* c = d.C + (i / d.N) * d.ldc + (i % d.N);
+      *c = acc ? *c + s : s;
+    }
+  }
 }
 }  // namespace b16x
 
@@ -845,7 +933,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
     }
     __syncthreads();
   }
-  write_tile<float, float, false>(p, acc, m0 + wrow, n0 + wcol, lane);
+  write_tile<float, float, false>(p, acc, m0 + wrow, n0 + wcol, lane, grid_slab());
 }
 }  // namespace f32
 
@@ -947,10 +1035,50 @@ int launch_gemm(K kernel, dim3 grid, size_t smem, hipStream_t stream, const Gemm
 }  // namespace
 
 // ============================================================================ host side
+static int gemm_one(int layout, const void* A, const void* B, void* C, const void* bias, const void* aux,
+                    int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, float alpha,
+                    int epilogue, int in_dtype, int out_dtype, void* workspace, int64_t workspace_bytes,
+                    void* stream_);
+
+// Entry point: validates nothing itself (gemm_one does) but cuts a long-K product whose 256-tiles
+// spill a few tiles into a further, mostly empty round of the chip into two row ranges: the tile
+// rows that fill whole rounds, and the remaining rows, which alone are fewer tiles than CUs and
+// therefore get split-K.  (35000 x 512 x 25k weight gradient: 274 tiles = one full round plus 18
+// tiles that would otherwise occupy 18 of 256 CUs for a second full-length round.)
 extern "C" int skhip_gemm(int layout, const void* A, const void* B, void* C, const void* bias, const void* aux,
                           int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, float alpha,
                           int epilogue, int in_dtype, int out_dtype, void* workspace, int64_t workspace_bytes,
                           void* stream_) {
+  const char* env_cut = getenv("SKHIP_GEMM_ROWCUT");
+  if (in_dtype == SK_BF16 && workspace && K >= 8192 && (layout == SK_GEMM_NT || layout == SK_GEMM_TN) && A && C &&
+      M > 0 && N > 0 &&
+      M < (1ll << 31) && N < (1ll << 31) && !(env_cut && env_cut[0] == '0')) {
+    const int64_t tm = (M + 255) / 256, tn = (N + 255) / 256, ncu = sk_num_cus();
+    const int64_t t256 = tm * tn, rounds = t256 / ncu, tail = t256 % ncu;
+    if (rounds >= 1 && rounds < 8 && tail > 0 && 2 * tail < ncu) {
+      const int64_t rows_full = rounds * ncu / tn;  // whole tile rows inside the full rounds
+      const int64_t M0 = rows_full * 256;
+      if (M0 > 0 && M0 < M) {
+        const int esz = 2, osz = out_dtype == SK_BF16 ? 2 : 4;
+        const char* A1 = (const char*)A + (layout == SK_GEMM_TN ? M0 : M0 * lda) * esz;
+        char* C1 = (char*)C + M0 * ldc * osz;
+        const char* aux1 = aux ? (const char*)aux + M0 * ldc * esz : nullptr;
+        int rc = gemm_one(layout, A, B, C, bias, aux, M0, N, K, lda, ldb, ldc, alpha, epilogue, in_dtype, out_dtype,
+                          workspace, workspace_bytes, stream_);
+        if (rc) return rc;
+        return gemm_one(layout, A1, B, C1, bias, aux1, M - M0, N, K, lda, ldb, ldc, alpha, epilogue, in_dtype,
+                        out_dtype, workspace, workspace_bytes, stream_);
+      }
+    }
+  }
+  return gemm_one(layout, A, B, C, bias, aux, M, N, K, lda, ldb, ldc, alpha, epilogue, in_dtype, out_dtype, workspace,
+                  workspace_bytes, stream_);
+}
+
+static int gemm_one(int layout, const void* A, const void* B, void* C, const void* bias, const void* aux,
+                    int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, float alpha,
+                    int epilogue, int in_dtype, int out_dtype, void* workspace, int64_t workspace_bytes,
+                    void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   SK_CHECK_ARG(layout >= 0 && layout <= 2, "skhip_gemm: bad layout %d", layout);
   SK_CHECK_ARG(in_dtype == SK_F32 || in_dtype == SK_BF16, "skhip_gemm: bad in_dtype %d", in_dtype);
@@ -1098,6 +1226,146 @@ extern "C" int skhip_gemm(int layout, const void* A, const void* B, void* C, con
     else
       hipLaunchKernelGGL((splitk_reduce_kernel<float, float>), dim3(rb), dim3(256), 0, stream, p, splits);
     SK_CHECK_LAUNCH("skhip_gemm(split-K reduce)");
+  }
+  return SK_OK;
+}
+
+// Grouped weight gradients: n independent products C_i (M_i x N_i fp32, row stride ldc_i) (+)= A_i^T B_i
+// with row-contiguous bf16 operands A_i (K_i x M_i, row stride lda_i), B_i (K_i x N_i, ldb_i), all in as
+// few launches as the 4 KB argument limit allows (48 sub-problems each).  `problems` is a HOST array
+// of n x 10 int64: {A, B, C, M, N, K, lda, ldb, ldc, accumulate}.  Scheduling: the 256-tiles of all
+// problems are laid out in order; those that fill whole rounds of the chip's CUs run unsplit, the
+// remainder (fewer tiles than CUs) is cut off at a tile-row boundary and K-split so that it, too,
+// occupies every CU once, with slabs in `workspace` and a reduction in split order (deterministic).
+extern "C" int skhip_gemm_grouped_tn(const int64_t* problems, int n, void* workspace, int64_t workspace_bytes,
+                                     void* stream_) {
+  using b16x::GroupArgs;
+  using b16x::GroupDesc;
+  hipStream_t stream = (hipStream_t)stream_;
+  SK_CHECK_ARG(n >= 0 && (n == 0 || problems), "skhip_gemm_grouped_tn: bad problem table");
+  if (n == 0) return SK_OK;
+  const int ncu = sk_num_cus();
+  int64_t total_tiles = 0;
+  for (int i = 0; i < n; ++i) {
+    const int64_t* q = problems + 10 * i;
+    const int64_t M = q[3], N = q[4], K = q[5], lda = q[6], ldb = q[7], ldc = q[8];
+    SK_CHECK_ARG(q[0] && q[1] && q[2], "skhip_gemm_grouped_tn: null operand in problem %d", i);
+    SK_CHECK_ARG(M > 0 && N > 0 && K > 0 && M < (1ll << 31) && N < (1ll << 31) && K < (1ll << 31) &&
+                 lda < (1ll << 31) && ldb < (1ll << 31) && ldc < (1ll << 31),
+                 "skhip_gemm_grouped_tn: bad shape in problem %d", i);
+    SK_CHECK_ARG(lda >= M && ldb >= N && ldc >= N, "skhip_gemm_grouped_tn: leading dimension too small in problem %d", i);
+    SK_CHECK_ARG(q[0] % 16 == 0 && q[1] % 16 == 0 && M % 8 == 0 && N % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && q[2] % 4 == 0,
+                 "skhip_gemm_grouped_tn: problem %d is not 16-byte aligned (operands, M, N, lda, ldb in elements of 8)", i);
+    total_tiles += ((M + 255) / 256) * ((N + 255) / 256);
+  }
+  SK_CHECK_ARG(total_tiles < (1ll << 30), "skhip_gemm_grouped_tn: too many tiles");
+
+  // ---- plan: sub-problems (row ranges) with their split counts
+  struct Sub { int prob; int64_t r0, r1; int splits; };
+  std::vector<Sub> subs;
+  const int64_t full_tiles = total_tiles / ncu * ncu;
+  auto max_splits_of = [&](int64_t K) { int64_t m = K / (4 * b16x::BK); return (int)(m < 1 ? 1 : m > 32 ? 32 : m); };
+  // K splits for `t` tiles that have the chip to themselves: the count that minimises rounds / splits
+  // (time in units of one unsplit tile), with a small charge per split for its slab traffic.
+  auto best_splits = [&](int64_t t) {
+    int best = 1;
+    double best_cost = 1e30;
+    for (int sp = 1; sp <= 32; ++sp) {
+      const double cost = (double)((t * sp + ncu - 1) / ncu) / sp + 0.02 * sp;
+      if (cost < best_cost - 1e-9) { best_cost = cost; best = sp; }
+    }
+    return best;
+  };
+  if (total_tiles < ncu) {  // not even one round: split everything alike
+    const int sp = best_splits(total_tiles);
+    for (int i = 0; i < n; ++i) subs.push_back({i, 0, problems[10 * i + 3], sp});
+  } else {
+    int64_t used = 0;
+    bool in_tail = false;
+    int64_t tail_tiles = 0;
+    std::vector<Sub> tail;
+    for (int i = 0; i < n; ++i) {
+      const int64_t M = problems[10 * i + 3], tn = (problems[10 * i + 4] + 255) / 256, tm = (M + 255) / 256;
+      if (in_tail) { tail.push_back({i, 0, M, 1}); tail_tiles += tm * tn; continue; }
+      if (used + tm * tn <= full_tiles) { subs.push_back({i, 0, M, 1}); used += tm * tn; continue; }
+      const int64_t rows_here = (full_tiles - used) / tn;  // whole tile rows that still fit the full rounds
+      if (rows_here > 0) subs.push_back({i, 0, rows_here * 256, 1});
+      tail.push_back({i, rows_here * 256, M, 1});
+      tail_tiles += (tm - rows_here) * tn;
+      used += rows_here * tn;
+      in_tail = true;
+    }
+    const int sp = tail_tiles > 0 ? best_splits(tail_tiles) : 1;
+    for (auto& t : tail) { t.splits = sp; subs.push_back(t); }
+  }
+
+  // one split count for all split sub-problems (they run as equal work items): lower it until the
+  // slabs of all of them fit the workspace
+  {
+    int sp = 1;
+    for (const Sub& sb : subs) sp = std::max(sp, sb.splits);
+    auto slab_bytes = [&](int spl) {
+      int64_t b = 0;
+      for (const Sub& sb : subs)
+        if (sb.splits > 1) {
+          const int64_t K = problems[10 * sb.prob + 5];
+          b += (int64_t)std::min(spl, max_splits_of(K)) * (sb.r1 - sb.r0) * problems[10 * sb.prob + 4] * 4;
+        }
+      return b;
+    };
+    while (sp > 1 && (!workspace || slab_bytes(sp) > workspace_bytes)) --sp;
+    for (Sub& sb : subs) sb.splits = std::min(sb.splits, sp);
+  }
+
+  // ---- descriptors, slabs
+  std::vector<GroupDesc> descs;
+  int64_t ws_used = 0;
+  for (const Sub& sb : subs) {
+    const int64_t* q = problems + 10 * sb.prob;
+    GroupDesc d;
+    d.M = (int)(sb.r1 - sb.r0); d.N = (int)q[4]; d.K = (int)q[5];
+    d.lda = (int)q[6]; d.ldb = (int)q[7]; d.ldc = (int)q[8];
+    d.A = (const char*)q[0] + sb.r0 * 2;
+    d.B = (const void*)q[1];
+    d.C = (float*)q[2] + sb.r0 * d.ldc;
+    int splits = sb.splits < max_splits_of(d.K) ? sb.splits : max_splits_of(d.K);
+    const int64_t slab = (int64_t)d.M * d.N * 4;
+    if (splits > 1 && ws_used + splits * slab > workspace_bytes) splits = 1;  // cannot happen after the uniform cut above
+    int kps = (d.K + splits - 1) / splits;
+    kps = (kps + b16x::BK - 1) / b16x::BK * b16x::BK;
+    splits = (d.K + kps - 1) / kps;
+    d.splits = splits; d.kps = kps;
+    d.ws = nullptr;
+    if (splits > 1) { d.ws = (float*)((char*)workspace + ws_used); ws_used += splits * slab; }
+    d.flags = (q[9] ? 1 : 0) | ((((uintptr_t)d.C % 16 == 0) && d.ldc % 4 == 0) ? 2 : 0);
+    d.first_block = 0;
+    descs.push_back(d);
+  }
+
+  // ---- launches, at most MAX_GROUP descriptors each
+  int rc = sk_allow_big_lds(b16x::gemm_grouped_tn_kernel, b16x::SMEM_BYTES);
+  if (rc) return rc;
+  for (size_t c0 = 0; c0 < descs.size(); c0 += b16x::MAX_GROUP) {
+    GroupArgs g;
+    g.n = (int)std::min<size_t>(b16x::MAX_GROUP, descs.size() - c0);
+    g.pad = 0;
+    int blocks = 0, max_red = 0;
+    for (int i = 0; i < g.n; ++i) {
+      g.d[i] = descs[c0 + i];
+      g.d[i].first_block = blocks;
+      const int tiles = ((g.d[i].M + 255) / 256) * ((g.d[i].N + 255) / 256);
+      blocks += tiles * g.d[i].splits;
+      if (g.d[i].splits > 1) {
+        const int64_t need = ((int64_t)g.d[i].M * g.d[i].N / 4 + 255) / 256;
+        max_red = (int)std::max<int64_t>(max_red, need < 1 ? 1 : need > 512 ? 512 : need);
+      }
+    }
+    hipLaunchKernelGGL(b16x::gemm_grouped_tn_kernel, dim3(blocks), dim3(512), b16x::SMEM_BYTES, stream, g);
+    SK_CHECK_LAUNCH("skhip_gemm_grouped_tn");
+    if (max_red > 0) {
+      hipLaunchKernelGGL(b16x::grouped_reduce_kernel, dim3(max_red, g.n), dim3(256), 0, stream, g);
+      SK_CHECK_LAUNCH("skhip_gemm_grouped_tn(reduce)");
+    }
   }
   return SK_OK;
 }

@@ -185,7 +185,9 @@ class TransformerModel(NMTModel):
             if idle:
                 loss, stats = loss * 0.0, stats * 0.0
             if not validation:
-                loss.backward()
+                # weight gradients of the layers run as grouped launches and land directly in .grad
+                with ops.batched_weight_grads(on_ready=self.reducer.mark_ready if self.reducer else None):
+                    loss.backward()
                 if self.reducer:
                     self.reducer.finish()
                 self.optimiser.step_and_update_lr()

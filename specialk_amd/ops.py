@@ -9,6 +9,8 @@ gradients are produced directly in fp32.
 import itertools
 import weakref
 
+import contextlib
+
 import torch
 
 from . import _lib as L
@@ -217,6 +219,96 @@ def _project(x, Ws, bs, out, ldc, dt):
         off += n
 
 
+# ----------------------------------------------------------------------------- batched weight gradients
+class _WeightGradBatch:
+    def __init__(self, on_ready, flush_tiles):
+        self.on_ready, self.flush_tiles = on_ready, flush_tiles
+        self.items, self.tiles, self.seen = [], 0, set()
+
+
+_wgrad_batch = None
+
+
+@contextlib.contextmanager
+def batched_weight_grads(on_ready=None, flush_tiles=256):
+    """Wrap `loss.backward()` in this context to compute the bf16 weight gradients of the attention and
+    feed-forward sub-layers in grouped launches instead of one split-K GEMM each.
+
+    Inside it, MHAFn / FFNFn hand autograd no gradient for their weight matrices; the products
+    dW = dy^T x are queued (their operands stay alive) and run together — whenever at least
+    `flush_tiles` 256 x 256 output tiles are waiting (one round of the chip) and when the context
+    exits — writing straight into `W.grad` (created if absent, accumulated into otherwise, so flat
+    gradient buckets keep working).  A (512, 512) weight is four tiles: alone it has to be cut into
+    dozens of K splits with their slab traffic to occupy the chip, in a group it is four of several
+    hundred equal work items.  on_ready(params) is called after each grouped launch with the
+    parameters whose gradients it wrote (a data-parallel reducer's cue; autograd hooks do not fire
+    for these parameters).  Bias, LayerNorm and embedding gradients still flow through autograd."""
+    global _wgrad_batch
+    if _wgrad_batch is not None:
+        raise RuntimeError("batched_weight_grads() does not nest")
+    _wgrad_batch = _WeightGradBatch(on_ready, flush_tiles)
+    try:
+        yield
+        _flush_weight_grads()
+    finally:
+        _wgrad_batch = None
+
+
+def _flush_weight_grads():
+    b = _wgrad_batch
+    if b is None or not b.items:
+        return
+    items, b.items, b.tiles, b.seen = b.items, [], 0, set()
+    problems, fixups, params = [], [], []
+    with torch.no_grad():
+        for dy, x, W, n, d_in, T in items:
+            g = W.grad
+            if g is None:
+                g = W.grad = torch.empty(W.shape, dtype=torch.float32, device=W.device)
+                acc, out = False, g
+            elif g.dtype == torch.float32 and g.is_contiguous():
+                acc, out = True, g
+            else:
+                acc, out = False, torch.empty(W.shape, dtype=torch.float32, device=W.device)
+                fixups.append((g, out))
+            problems.append((dy, x, out, n, d_in, T, dy.stride(0), x.stride(0), d_in, acc))
+            params.append(W)
+        L.gemm_grouped_tn(problems)
+        for g, out in fixups:
+            g.add_(out)
+    if b.on_ready is not None:
+        b.on_ready(params)
+
+
+def _weight_grad(dy, x, W, T, needed=True):
+    """dW (n, d_in) = dy (T, n; any row stride)^T x (T, d_in) for the weight W of shape (n, d_in[, 1]):
+    returned for autograd, or — inside batched_weight_grads(), bf16 only — queued for the next grouped
+    launch, in which case None is returned and W.grad is written by that launch."""
+    if not needed:
+        return None
+    n, d_in = dy.shape[1], x.shape[1]
+    b = _wgrad_batch
+    if b is None or dy.dtype != torch.bfloat16 or dy.stride(0) % 8 or x.stride(0) % 8 or n % 8 or d_in % 8 \
+            or dy.data_ptr() % 16 or x.data_ptr() % 16:
+        return L.gemm(L.GEMM_TN, dy, x, n, d_in, T, dy.stride(0), x.stride(0), out_dtype=torch.float32).view(W.shape)
+    if W.data_ptr() in b.seen:  # two products into one gradient must not share a launch
+        _flush_weight_grads()
+    b.seen.add(W.data_ptr())
+    b.items.append((dy, x, W, n, d_in, T))
+    b.tiles += ((n + 255) // 256) * ((d_in + 255) // 256)
+    if b.tiles >= b.flush_tiles:
+        _flush_weight_grads()
+    return None
+
+
+def _unalias(dres, dy):
+    """The residual-branch gradient is accumulated into in place; with dropout off it shares dy's
+    storage, which queued weight-gradient products still have to read."""
+    if dres is not None and _wgrad_batch is not None and dres.data_ptr() == dy.data_ptr():
+        return dres.clone()
+    return dres
+
+
 # ----------------------------------------------------------------------------- linear
 class LinearFn(torch.autograd.Function):
     """y = alpha * x W^T + b   (nn.Linear; lib/transformer/SubLayers.py:46-48,62, Models.py:278)."""
@@ -272,13 +364,14 @@ class FFNFn(torch.autograd.Function):
         x, h, W1, W2 = ctx.saved_tensors
         dres = _residual_grad(dy)
         dy = dy.contiguous()
+        dres = _unalias(dres, dy)
         T, d = x.shape
         F = _as2d(W1)[0]
         dh = _input_grad(dy, d, (W2,), T, F, x.dtype, aux=h, epilogue=L.EPI_RELU_MASK)
-        dW2 = L.gemm(L.GEMM_TN, dy, h, d, F, T, d, F, out_dtype=torch.float32).view(W2.shape)
+        dW2 = _weight_grad(dy, h, W2, T, ctx.needs_input_grad[3])
         db2 = _bias_grad(dy, T, d)
-        dx = _input_grad(dh, F, (W1,), T, d, x.dtype, add_to=dres)  # dy is not read after this line
-        dW1 = L.gemm(L.GEMM_TN, dh, x, F, d, T, F, x.stride(0), out_dtype=torch.float32).view(W1.shape)
+        dx = _input_grad(dh, F, (W1,), T, d, x.dtype, add_to=dres)  # accumulates into dres in place
+        dW1 = _weight_grad(dh, x, W1, T, ctx.needs_input_grad[1])
         db1 = L.colsum(dh, T, F, F)
         return dx, dW1, db1, dW2, db2
 
@@ -341,10 +434,12 @@ class MHAFn(torch.autograd.Function):
         ldq, ldk, ldv = ctx.lds
         dres = _residual_grad(dout)
         dout = dout.contiguous()
+        dres = _unalias(dres, dout)
         f32 = torch.float32
+        need = ctx.needs_input_grad
         # output projection
         dO = _input_grad(dout, d, (Wo,), Tq, nv, dt)
-        dWo = L.gemm(L.GEMM_TN, dout, O, d, nv, Tq, d, nv, out_dtype=f32)
+        dWo = _weight_grad(dout, O, Wo, Tq, need[8])
         dbo = _bias_grad(dout, Tq, d)
         # attention core
         if cfg["self_attn"]:
@@ -362,21 +457,30 @@ class MHAFn(torch.autograd.Function):
                    p_drop=cfg["p_attn"], seed=ctx.seed, q_off=cfg.get("q_off"), k_off=cfg.get("k_off"))
         # projections: weight gradients, bias gradients (column sums) and input gradients, each over the
         # widest buffer that shares an input ([dq|dk|dv] for self-attention, [dk|dv] otherwise)
+        batched = _wgrad_batch is not None and dt == torch.bfloat16
         if cfg["self_attn"]:
             n3 = nq + nk + nv
-            dW = L.gemm(L.GEMM_TN, dqkv, q_in, n3, d, Tq, lddq, q_in.stride(0), out_dtype=f32)
+            if batched:  # one problem per parameter, each written straight into its .grad
+                dWq, dWk, dWv = (_weight_grad(g, q_in, W, Tq, nd) for g, W, nd in
+                                 ((dQ, Wq, need[2]), (dK, Wk, need[4]), (dV, Wv, need[6])))
+            else:
+                dW = L.gemm(L.GEMM_TN, dqkv, q_in, n3, d, Tq, lddq, q_in.stride(0), out_dtype=f32)
+                dWq, dWk, dWv = dW[:nq], dW[nq:nq + nk], dW[nq + nk:]
             db = L.colsum(dqkv, Tq, n3, lddq)
-            dWq, dWk, dWv = dW[:nq], dW[nq:nq + nk], dW[nq + nk:]
             dbq, dbk, dbv = db[:nq], db[nq:nq + nk], db[nq + nk:]
-            dq_in = _input_grad(dqkv, lddq, (Wq, Wk, Wv), Tq, d, dt, add_to=dres)  # dout is not read after this
+            dq_in = _input_grad(dqkv, lddq, (Wq, Wk, Wv), Tq, d, dt, add_to=dres)  # accumulates into dres in place
             dkv_in = None
         else:
-            dWq = L.gemm(L.GEMM_TN, dQ, q_in, nq, d, Tq, lddq, q_in.stride(0), out_dtype=f32)
+            dWq = _weight_grad(dQ, q_in, Wq, Tq, need[2])
             dbq = L.colsum(dQ, Tq, nq, lddq)
-            dW = L.gemm(L.GEMM_TN, dkv, kv_in, nk + nv, d, Tk, lddk, kv_in.stride(0), out_dtype=f32)
+            if batched:
+                dWk, dWv = _weight_grad(dK, kv_in, Wk, Tk, need[4]), _weight_grad(dV, kv_in, Wv, Tk, need[6])
+            else:
+                dW = L.gemm(L.GEMM_TN, dkv, kv_in, nk + nv, d, Tk, lddk, kv_in.stride(0), out_dtype=f32)
+                dWk, dWv = dW[:nk], dW[nk:]
             db = L.colsum(dkv, Tk, nk + nv, lddk)
-            dWk, dWv, dbk, dbv = dW[:nk], dW[nk:], db[:nk], db[nk:]
-            dq_in = _input_grad(dQ, lddq, (Wq,), Tq, d, dt, add_to=dres)  # dout is not read after this
+            dbk, dbv = db[:nk], db[nk:]
+            dq_in = _input_grad(dQ, lddq, (Wq,), Tq, d, dt, add_to=dres)  # accumulates into dres in place
             dkv_in = _input_grad(dkv, lddk, (Wk, Wv), Tk, d, dt)
         return dq_in, dkv_in, dWq, dbq, dWk, dbk, dWv, dbv, dWo, dbo, None
 

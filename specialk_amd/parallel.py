@@ -46,6 +46,7 @@ class GradBucketReducer:
         # finish(); in-backward overlap is only for RCCL, which reduces the device buffers in place.
         self._staged = (self.world > 1 and self.buckets and self.buckets[0][0].is_cuda
                         and dist.get_backend(process_group) != "nccl")
+        self._bucket_of = {p.data_ptr(): bi for bi, (_, plist) in enumerate(self.buckets) for p in plist}
         if self.world > 1 and not self._staged:
             for bi, (_, plist) in enumerate(self.buckets):
                 for p in plist:
@@ -67,6 +68,13 @@ class GradBucketReducer:
                 flat = self.buckets[bi][0]
                 self._handles.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         return hook
+
+    def mark_ready(self, params):
+        """Cue for gradients that were written into the bucket views directly instead of being
+        accumulated by autograd (ops.batched_weight_grads): counts them like the hooks do."""
+        if self.world > 1 and not self._staged:
+            for p in params:
+                self._make_hook(self._bucket_of[p.data_ptr()])(p)
 
     def zero_grad(self):
         """Zero the flat buckets in place (gradient views stay attached to the parameters)."""

@@ -124,11 +124,36 @@ def _dp_worker(rank, world, port, out):
     y = torch.randn(8, 3, generator=torch.Generator().manual_seed(2))
     per = 8 // world
     res = []
+    direct = []
+
+    class DirectGradLinear(torch.autograd.Function):
+        """A layer that, like ops.batched_weight_grads, writes its weight gradient into .grad itself
+        and hands autograd None for it: the reducer learns about it through mark_ready()."""
+
+        @staticmethod
+        def forward(ctx, inp, W, b):
+            ctx.save_for_backward(inp, W)
+            return inp @ W.t() + b
+
+        @staticmethod
+        def backward(ctx, dy):
+            inp, W = ctx.saved_tensors
+            W.grad.add_(dy.t() @ inp)
+            direct.append(W)
+            return dy @ W, None, dy.sum(0)
+
+    def run(xs):
+        h = torch.tanh(net[0](xs))
+        h = torch.tanh(DirectGradLinear.apply(h, net[2].weight, net[2].bias))
+        return net[4](h)
+
     for it in range(2):                                       # second pass checks zero_grad / hook re-arming
         red.zero_grad()
         xs, ys = x[rank * per:(rank + 1) * per], y[rank * per:(rank + 1) * per]
-        loss = ((net(xs) - ys) ** 2).sum() * (it + 1)
+        loss = ((run(xs) - ys) ** 2).sum() * (it + 1)
         loss.backward()
+        red.mark_ready(direct)
+        del direct[:]
         red.finish()
         res.append([p.grad.clone() for p in params])
     tot = all_reduce_scalars([float(rank + 1), 2.0, 0.5], "cpu")

@@ -96,7 +96,7 @@ def test_gemm_bf16_kernel_variants(L, env):
     old = {k: os.environ.get(k) for k in ("SKHIP_GEMM_BIG", "SKHIP_GEMM_STAGED")}
     os.environ.update(env)
     try:
-        # the last shape has more 256-tiles (18 x 17) than the chip has CUs: the persistent kernel walks several tiles per block
+        # the last shape has more 256-tiles (18 x 17) than the chip has CUs
         for (M, N, K) in [(256, 256, 32), (700, 520, 200), (1000, 264, 1096), (513, 8, 72), (3, 1000, 8), (4600, 4100, 104)]:
             A, B = rnd((M, K), torch.bfloat16, g), rnd((N, K), torch.bfloat16, g)
             bias = torch.randn(N, generator=g)
@@ -118,6 +118,57 @@ def test_gemm_bf16_kernel_variants(L, env):
     finally:
         for k, v in old.items():
             os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+
+
+def test_gemm_bf16_row_cut(L):
+    """Long-K products whose 256-tiles overflow the CUs by a few tiles are computed as two row
+    ranges (the second with split-K); operands, output and the ReLU-mask operand must all be
+    offset consistently."""
+    g = torch.Generator(device=DEV).manual_seed(5)
+    M, N, K = 33300, 512, 8200  # 131 x 2 tiles = 256 + 6
+    A = torch.randn((K, M), device=DEV, generator=g).to(torch.bfloat16)
+    B = torch.randn((K, N), device=DEV, generator=g).to(torch.bfloat16)
+    out = L.gemm(L.GEMM_TN, A, B, M, N, K, M, N, out_dtype=torch.float32)
+    ref = A.double().t() @ B.double()
+    assert rel_err(out.cpu(), ref.cpu()) <= 1e-5
+    An = A.t().contiguous()
+    Bn = B.t().contiguous()
+    aux = torch.randn((M, N), device=DEV, generator=g).to(torch.bfloat16)
+    bias = torch.randn(N, device=DEV, generator=g)
+    out = L.gemm(L.GEMM_NT, An, Bn, M, N, K, K, K, bias=bias, aux=aux, epilogue=L.EPI_RELU_MASK)
+    ref = torch.where(aux.double() > 0, ref + bias.double(), torch.zeros_like(ref))
+    assert rel_err(out.cpu(), ref.cpu()) <= BF16_RTOL
+
+
+@pytest.mark.parametrize("case", ["split_all", "full_round_and_tail", "many_problems"])
+def test_gemm_grouped_tn(L, case):
+    """Grouped weight-gradient products: fewer tiles than CUs (everything K-split), a full round of
+    tiles plus a K-split remainder cut inside a problem, and more problems than one launch's
+    argument table holds; strided operand slices and accumulation into C."""
+    g = torch.Generator(device=DEV).manual_seed(17)
+    rn = lambda *shape: torch.randn(shape, device=DEV, generator=g).to(torch.bfloat16)
+    probs, refs = [], []
+
+    def add(M, N, K, acc, a_pad=0):
+        A_full, B = rn(K, M + a_pad), rn(K, N)
+        A = A_full[:, a_pad:]  # a column slice of a wider buffer, like dq|dk|dv
+        C = torch.randn((M, N), device=DEV, generator=g) if acc else torch.full((M, N), float("nan"), device=DEV)
+        refs.append((C, (C.double() if acc else 0) + A.double().t() @ B.double()))
+        probs.append((A, B, C, M, N, K, A_full.stride(0), N, N, acc))
+
+    if case == "split_all":
+        add(512, 512, 3000, False); add(512, 512, 3000, True, a_pad=1024); add(2048, 512, 3000, True)
+        add(8, 264, 1000, False); add(520, 2048, 2999, False, a_pad=8)
+    elif case == "full_round_and_tail":
+        for i in range(20):
+            add(2048, 512, 1100, i % 2 == 0)
+        add(1000, 264, 1100, False)
+    else:
+        for i in range(60):
+            add(256 + 8 * (i % 3), 264, 200 + i, i % 3 == 0)
+    L.gemm_grouped_tn(probs)
+    for i, (C, ref) in enumerate(refs):
+        assert rel_err(C, ref) <= 1e-5, (case, i)
 
 
 def test_colsum(L):
