@@ -361,8 +361,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(AttnParams p) {
 // re-read every operand from HBM.
 template <int D>
 __global__ __launch_bounds__(256) void attn_bwd_fused_mfma_kernel(AttnParams p) {
-  __shared__ __attribute__((aligned(16))) Tile<D> Ks;
-  __shared__ __attribute__((aligned(16))) Tile<D> Vs;
+  // K and V tiles; after phase A their storage holds P and dS (64 x 64, query-major)
+  __shared__ __attribute__((aligned(16))) char ks_raw[sizeof(Tile<(D > 64 ? D : 64)>)];
+  __shared__ __attribute__((aligned(16))) char vs_raw[sizeof(Tile<(D > 64 ? D : 64)>)];
+  Tile<D>& Ks = *(Tile<D>*)ks_raw;
+  Tile<D>& Vs = *(Tile<D>*)vs_raw;
+  Tile<64>& Ps = *(Tile<64>*)ks_raw;
+  Tile<64>& dSs = *(Tile<64>*)vs_raw;
   __shared__ __attribute__((aligned(16))) Tile<D> Qs;
   __shared__ __attribute__((aligned(16))) Tile<D> dOs;
   __shared__ uint8_t kmask[OT];
@@ -412,7 +417,7 @@ __global__ __launch_bounds__(256) void attn_bwd_fused_mfma_kernel(AttnParams p) 
       fdo[s] = *(const bf16x8_t*)&dOs.a[q][32 * s + 8 * g];
     }
     const float lse = s_lse[q], dl = s_dl[q];
-    f32x4_t ds[4];
+    f32x4_t ds[4], pd[4];
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) {
       f32x4_t sc = f32x4_t{0.f, 0.f, 0.f, 0.f}, dp = f32x4_t{0.f, 0.f, 0.f, 0.f};
@@ -427,8 +432,13 @@ __global__ __launch_bounds__(256) void attn_bwd_fused_mfma_kernel(AttnParams p) 
         const int jl = 16 * kt + 4 * g + r;
         const bool msk = kmask[jl] || (p.causal && jl > q) || q >= Lq;
         const float pr = msk ? 0.f : __expf(sc[r] * p.scale - lse);
-        float dpv = dp[r];
-        if (p.drop_thr) dpv = (km >> r) & 1 ? dpv * p.keep_scale : 0.f;
+        float dpv = dp[r], pdv = pr;
+        if (p.drop_thr) {
+          const bool kp = (km >> r) & 1;
+          dpv = kp ? dpv * p.keep_scale : 0.f;
+          pdv = kp ? pr * p.keep_scale : 0.f;
+        }
+        pd[kt][r] = pdv;
         ds[kt][r] = pr * (dpv - dl) * p.scale;
       }
     }
@@ -452,44 +462,28 @@ __global__ __launch_bounds__(256) void attn_bwd_fused_mfma_kernel(AttnParams p) 
         *(uint2*)(out + 16 * t + 4 * g) = w;
       }
     }
+    // P (with the dropout scaling) and dS of the own query row replace the K and V tiles, which
+    // no wave reads any more after the barrier; phase B then takes them as transposed operands
+    // instead of recomputing scores, exponentials and dropout decisions for its key rows
+    __syncthreads();
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      uint2 wp, wd;
+      bf16_t* ep = (bf16_t*)&wp;
+      bf16_t* ed = (bf16_t*)&wd;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { ep[r] = f32_to_bf16(pd[kt][r]); ed[r] = f32_to_bf16(ds[kt][r]); }
+      *(uint2*)&Ps.a[q][16 * kt + 4 * g] = wp;
+      *(uint2*)&dSs.a[q][16 * kt + 4 * g] = wd;
+    }
+    __syncthreads();
   }
 
-  // ---- phase B: own key rows -> dK, dV
+  // ---- phase B: own key rows -> dK = dS^T Q, dV = P^T dO
   {
     const int j = own;
-    bf16x8_t fk[D / 32], fv[D / 32];
-#pragma unroll
-    for (int s = 0; s < D / 32; ++s) {
-      fk[s] = *(const bf16x8_t*)&Ks.a[j][32 * s + 8 * g];
-      fv[s] = *(const bf16x8_t*)&Vs.a[j][32 * s + 8 * g];
-    }
-    const bool jmask = kmask[j];
-    f32x4_t pd[4], ds[4];
-#pragma unroll
-    for (int qt = 0; qt < 4; ++qt) {
-      f32x4_t sc = f32x4_t{0.f, 0.f, 0.f, 0.f}, dp = f32x4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int s = 0; s < D / 32; ++s) {
-        sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x_rows<D>(Qs, 16 * qt, s, lane), fk[s], sc, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x_rows<D>(dOs, 16 * qt, s, lane), fv[s], dp, 0, 0, 0);
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int i = 16 * qt + 4 * g + r;
-        const bool msk = jmask || i >= Lq || (p.causal && j > i);
-        const float pr = msk ? 0.f : __expf(sc[r] * p.scale - s_lse[i]);
-        float dpv = dp[r], pdv = pr;
-        if (p.drop_thr) {
-          const bool kp = keep(p, b, h, i, j);
-          dpv = kp ? dpv * p.keep_scale : 0.f;
-          pdv = kp ? pr * p.keep_scale : 0.f;
-        }
-        pd[qt][r] = pdv;
-        ds[qt][r] = pr * (dpv - s_dl[i]) * p.scale;
-      }
-    }
-    const bf16x8_t yp0 = pack_y(pd[0], pd[1]), yp1 = pack_y(pd[2], pd[3]);
-    const bf16x8_t ys0 = pack_y(ds[0], ds[1]), ys1 = pack_y(ds[2], ds[3]);
+    const bf16x8_t yp0 = x_cols<64>(Ps, 16 * wave, 0, lane), yp1 = x_cols<64>(Ps, 16 * wave, 1, lane);
+    const bf16x8_t ys0 = x_cols<64>(dSs, 16 * wave, 0, lane), ys1 = x_cols<64>(dSs, 16 * wave, 1, lane);
     f32x4_t dk[D / 16], dv[D / 16];
 #pragma unroll
     for (int t = 0; t < D / 16; ++t) {
