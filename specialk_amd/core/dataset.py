@@ -24,6 +24,69 @@ def paired_collate_fn(insts):
     return (*collate_fn(src_insts), *collate_fn(tgt_insts))
 
 
+class TokenBudgetBatchSampler(torch.utils.data.Sampler):
+    """Length-bucketed batches under a token budget, for `DataLoader(batch_sampler=...)`.
+
+    The reference draws a fixed number of sentences per batch from a shuffled dataset
+    (lib/nmtModel.py:356-367), so a batch is as long as its longest sentence and the work per
+    step varies with the draw.  Here every epoch the indices are shuffled, cut into pools of
+    `pool_batches` x `max_sentences` sentences, sorted by length inside each pool (neighbours in a
+    batch have similar lengths: little padding in the id tensors, similar sequence lengths in the
+    attention kernels) and cut greedily into batches of at most `max_tokens` tokens (a sentence
+    counts max(len(src), len(tgt))) and `max_sentences` sentences; the batches are then shuffled.
+    Every index appears exactly once per epoch; the order is a function of (seed, epoch) only, so
+    all ranks of a data-parallel run iterate the same batches (each takes its shard of them)."""
+
+    def __init__(self, lengths, max_tokens, max_sentences=1024, pool_batches=64, shuffle=True, seed=0):
+        self.lengths = np.asarray(lengths, dtype=np.int64)
+        if max_tokens < 1 or max_sentences < 1:
+            raise ValueError("max_tokens and max_sentences must be positive")
+        self.max_tokens, self.max_sentences = int(max_tokens), int(max_sentences)
+        self.pool, self.shuffle, self.seed, self.epoch = int(pool_batches) * int(max_sentences), shuffle, seed, 0
+        self._cache = None
+
+    @classmethod
+    def for_dataset(cls, ds, max_tokens, **kw):
+        tgt = ds._tgt_insts or ds._src_insts
+        return cls([max(len(a), len(b)) for a, b in zip(ds._src_insts, tgt)], max_tokens, **kw)
+
+    def set_epoch(self, epoch):
+        self.epoch, self._cache = int(epoch), None
+
+    def _batches(self):
+        if self._cache is not None and self._cache[0] == self.epoch:
+            return self._cache[1]
+        n = len(self.lengths)
+        rng = np.random.default_rng([self.seed, self.epoch])
+        order = rng.permutation(n) if self.shuffle else np.arange(n)
+        batches = []
+        for p0 in range(0, n, self.pool):
+            pool = order[p0:p0 + self.pool]
+            pool = pool[np.argsort(self.lengths[pool], kind="stable")]
+            cur, tokens = [], 0
+            for i in pool.tolist():
+                c = int(self.lengths[i])
+                if cur and (tokens + c > self.max_tokens or len(cur) == self.max_sentences):
+                    batches.append(cur)
+                    cur, tokens = [], 0
+                cur.append(i)
+                tokens += c
+            if cur:
+                batches.append(cur)
+        if self.shuffle:
+            batches = [batches[i] for i in rng.permutation(len(batches)).tolist()]
+        self._cache = (self.epoch, batches)
+        return batches
+
+    def __iter__(self):
+        batches = self._batches()
+        self.set_epoch(self.epoch + 1)  # a plain `for batch in loader` per epoch reshuffles by itself
+        return iter(batches)
+
+    def __len__(self):
+        return len(self._batches())
+
+
 class TranslationDataset(torch.utils.data.Dataset):
     """Same constructor, properties and item protocol as core/dataset.py:49-105."""
 

@@ -16,7 +16,7 @@ import torch
 import torch.utils.data
 
 from ..core import constants
-from ..core.dataset import TranslationDataset, collate_fn, paired_collate_fn
+from ..core.dataset import TokenBudgetBatchSampler, TranslationDataset, collate_fn, paired_collate_fn
 
 
 def _rank():
@@ -153,6 +153,11 @@ class NMTModel:
         def loader(split, shuffle):
             ds = TranslationDataset(src_word2idx=src_word2idx, tgt_word2idx=tgt_word2idx,
                                     src_insts=data[split]["src"], tgt_insts=data[split]["tgt"])
+            budget = int(getattr(opt, "batch_tokens", 0) or 0)
+            if budget > 0:  # length-bucketed batches of at most `budget` tokens and -batch_size sentences
+                sampler = TokenBudgetBatchSampler.for_dataset(ds, budget, max_sentences=opt.batch_size, shuffle=shuffle,
+                                                              seed=int(getattr(opt, "seed", 0) or 0))
+                return torch.utils.data.DataLoader(ds, num_workers=0, batch_sampler=sampler, collate_fn=paired_collate_fn)
             return torch.utils.data.DataLoader(ds, num_workers=0, batch_size=opt.batch_size,
                                                collate_fn=paired_collate_fn, shuffle=shuffle)
         train_loader, valid_loader = loader("train", True), loader("valid", False)

@@ -73,6 +73,9 @@ def load_args():
     p.add_argument("-dtype", default="fp32", choices=["fp32", "bf16"],
                    help="arithmetic of the matrix products (fp32 master weights either way)")
     p.add_argument("-seed", type=int, default=0, help="seed of initialisation, shuffling and dropout")
+    p.add_argument("-batch_tokens", type=int, default=0,
+                   help="> 0: length-bucketed batches of at most this many tokens (and -batch_size sentences) "
+                        "instead of the reference's fixed sentence count")
     return p
 
 

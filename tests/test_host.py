@@ -204,3 +204,35 @@ def test_batch_shard_covers_batch_without_overlap(monkeypatch):
             sh = TM.TransformerModel._shard(None, batch)
             seen += sh[0][:, 0].tolist()
         assert seen == list(range(10))
+
+
+# ---------------------------------------------------------------- token-budget batching
+def test_token_budget_sampler_covers_every_sentence_once_within_budget():
+    from specialk_amd.core.dataset import TokenBudgetBatchSampler, TranslationDataset, paired_collate_fn
+    rng = np.random.default_rng(0)
+    n = 3000
+    src = [[2] + rng.integers(5, 99, rng.integers(3, 50)).tolist() + [3] for _ in range(n)]
+    tgt = [[2] + rng.integers(5, 99, rng.integers(3, 50)).tolist() + [3] for _ in range(n)]
+    w2i = {str(i): i for i in range(100)}
+    ds = TranslationDataset(w2i, w2i, src, tgt)
+    sm = TokenBudgetBatchSampler.for_dataset(ds, 2000, max_sentences=64, pool_batches=8, seed=5)
+    cost = np.array([max(len(a), len(b)) for a, b in zip(src, tgt)])
+    e0 = list(sm)            # epoch 0; iterating advances the epoch
+    e1 = list(sm)
+    for batches in (e0, e1):
+        flat = sorted(i for b in batches for i in b)
+        assert flat == list(range(n))
+        assert all(cost[b].sum() <= 2000 and len(b) <= 64 for b in batches)
+    assert e0 != e1
+    sm2 = TokenBudgetBatchSampler.for_dataset(ds, 2000, max_sentences=64, pool_batches=8, seed=5)
+    assert list(sm2) == e0 and len(sm2) == len(e1)   # a function of (seed, epoch) only
+    # bucketing: padded size close to the real token count (unsorted batches of 64 waste ~2x)
+    padded = sum(len(b) * cost[b].max() for b in e0)
+    assert padded <= 1.1 * cost.sum()
+    # a sentence longer than the budget still gets a batch of its own
+    lone = TokenBudgetBatchSampler([5, 3000, 7], 100, shuffle=False)
+    assert sorted(map(sorted, lone)) == [[0, 2], [1]]
+    # the DataLoader contract: batch_sampler + the reference's collate function
+    loader = torch.utils.data.DataLoader(ds, batch_sampler=sm2, collate_fn=paired_collate_fn)
+    s_seq, s_pos, t_seq, t_pos = next(iter(loader))
+    assert s_seq.shape == s_pos.shape and t_seq.shape[0] == s_seq.shape[0] <= 64
