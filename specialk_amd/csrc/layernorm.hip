@@ -7,6 +7,9 @@
 // the statistics and the normalisation, so each element is read once and written once.
 // Statistics are fp32 and two-pass (mean, then centred variance) like torch's.
 #include "common.h"
+#include <algorithm>
+#include <map>
+#include <mutex>
 
 namespace {
 
@@ -278,6 +281,18 @@ int check_d(const char* who, int d, int dtype) {
   return SK_OK;
 }
 
+// Blocks of 256 threads of `kernel` that are resident on the whole chip at once (cached per kernel).
+int64_t resident_blocks(const void* kernel, size_t smem) {
+  static std::mutex mu;
+  static std::map<const void*, int64_t> cache;
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = cache.find(kernel);
+  if (it != cache.end()) return it->second;
+  int per_cu = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, smem) != hipSuccess || per_cu < 1) per_cu = 1;
+  return cache[kernel] = (int64_t)per_cu * sk_num_cus();
+}
+
 }  // namespace
 
 extern "C" int skhip_add_ln_fwd(const void* x, const void* res, const float* gamma, const float* beta,
@@ -294,14 +309,17 @@ extern "C" int skhip_add_ln_fwd(const void* x, const void* res, const float* gam
   if (blocks < 1) blocks = 1;
   uint32_t thr = sk_drop_threshold(p_drop);
   float ks = 1.0f / (1.0f - p_drop);
+  // the grid is one resident round of the chip (the waves stride over the rows): a few blocks more
+  // than fit at once would run as a second, mostly empty round
 #define LN_FWD(TT, MV)                                                                                          \
+  blocks = std::min<int64_t>(blocks, resident_blocks((const void*)add_ln_fwd_kernel<TT, MV>, 0));              \
   hipLaunchKernelGGL((add_ln_fwd_kernel<TT, MV>), dim3((unsigned)blocks), dim3(256), 0, stream, (const TT*)x,   \
                      (const TT*)res, gamma, beta, row_pad, (TT*)y, mean, rstd, T, d, eps, thr, ks, seed)
   const int nvl = (d / (dtype == SK_BF16 ? 8 : 4) + 63) / 64;  // 16-byte vectors per lane
   if (dtype == SK_BF16) {
-    if (nvl <= 1) LN_FWD(bf16_t, 1); else if (nvl <= 2) LN_FWD(bf16_t, 2); else LN_FWD(bf16_t, 4);
+    if (nvl <= 1) { LN_FWD(bf16_t, 1); } else if (nvl <= 2) { LN_FWD(bf16_t, 2); } else { LN_FWD(bf16_t, 4); }
   } else {
-    if (nvl <= 2) LN_FWD(float, 2); else if (nvl <= 4) LN_FWD(float, 4); else LN_FWD(float, 8);
+    if (nvl <= 2) { LN_FWD(float, 2); } else if (nvl <= 4) { LN_FWD(float, 4); } else { LN_FWD(float, 8); }
   }
 #undef LN_FWD
   SK_CHECK_LAUNCH("skhip_add_ln_fwd");
@@ -328,14 +346,15 @@ extern "C" int skhip_add_ln_bwd(const void* dy, const void* x, const void* res, 
   float ks = 1.0f / (1.0f - p_drop);
   size_t smem = (size_t)4 * LN_NPART * d * sizeof(float);
 #define LN_BWD(TT, MV)                                                                                            \
+  blocks = std::min<int64_t>(blocks, resident_blocks((const void*)add_ln_bwd_kernel<TT, MV>, smem));             \
   hipLaunchKernelGGL((add_ln_bwd_kernel<TT, MV>), dim3((unsigned)blocks), dim3(256), smem, stream, (const TT*)dy, \
                      (const TT*)x, (const TT*)res, gamma, row_pad, mean, rstd, (TT*)dx, (TT*)dres, partial_ws, T, \
                      d, thr, ks, seed)
   const int nvl = (d / (dtype == SK_BF16 ? 8 : 4) + 63) / 64;  // 16-byte vectors per lane
   if (dtype == SK_BF16) {
-    if (nvl <= 1) LN_BWD(bf16_t, 1); else if (nvl <= 2) LN_BWD(bf16_t, 2); else LN_BWD(bf16_t, 4);
+    if (nvl <= 1) { LN_BWD(bf16_t, 1); } else if (nvl <= 2) { LN_BWD(bf16_t, 2); } else { LN_BWD(bf16_t, 4); }
   } else {
-    if (nvl <= 2) LN_BWD(float, 2); else if (nvl <= 4) LN_BWD(float, 4); else LN_BWD(float, 8);
+    if (nvl <= 2) { LN_BWD(float, 2); } else if (nvl <= 4) { LN_BWD(float, 4); } else { LN_BWD(float, 8); }
   }
 #undef LN_BWD
   SK_CHECK_LAUNCH("skhip_add_ln_bwd");
