@@ -147,6 +147,113 @@ __global__ __launch_bounds__(256) void xent_kernel(const T* __restrict__ logits,
   }
 }
 
+// Register-resident variant for bf16 rows of up to NV * 2048 elements: each thread loads its NV
+// 16-byte vectors of the row once (all loads in flight together), the statistics and the
+// gradient are computed from registers, so the row is read from memory exactly once and written
+// once — the two-sweep kernel above reads it a second time, and with V = 35000 the rows in flight
+// do not fit the L2s, so that second read also comes from beyond L2.
+// element j (0..7) of a 16-byte vector of bf16 as fp32, by register arithmetic only (taking the
+// address of the vector would move the whole row array to scratch memory)
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float vec_elem(const u32x4_t v, int j) {
+  const uint32_t w = v[j >> 1];
+  return __uint_as_float((j & 1) ? (w & 0xffff0000u) : (w << 16));
+}
+
+template <int NV>
+__global__ __launch_bounds__(256, (NV <= 8 ? 4 : 3)) void xent_rowreg_kernel(const bf16_t* __restrict__ logits,
+                                                          const int64_t* __restrict__ gold, bf16_t* dlogits,
+                                                          double* __restrict__ stats, int64_t T_rows, int V, int64_t ldl,
+                                                          float logit_scale, float eps, int64_t pad_id, float grad_scale) {
+  const int nvec = V >> 3;
+  for (int64_t row = blockIdx.x; row < T_rows; row += gridDim.x) {
+    const int64_t g = gold[row];
+    const bf16_t* x = logits + row * ldl;
+    bf16_t* dx = dlogits ? dlogits + row * ldl : nullptr;
+    if (g == pad_id) {  // block-uniform
+      if (dx)
+        for (int i = threadIdx.x; i < nvec; i += 256) *(uint4*)(dx + 8 * (int64_t)i) = make_uint4(0, 0, 0, 0);
+      continue;
+    }
+    u32x4_t r[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int i = threadIdx.x + 256 * k;
+      r[k] = i < nvec ? *(const u32x4_t*)(x + 8 * (int64_t)i) : u32x4_t{0, 0, 0, 0};
+    }
+    // ---- statistics from registers: local max / plain sum / arg max, then sum-exp against the local max
+    float mx = -INFINITY, sx = 0.f, amv = -INFINITY;
+    int am = 0x7fffffff;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int i = threadIdx.x + 256 * k;
+      if (i < nvec) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float v = vec_elem(r[k], j) * logit_scale;
+          sx += v;
+          if (v > amv) { amv = v; am = 8 * k + j; }  // position inside this thread's registers (a constant)
+        }
+      }
+    }
+    if (am != 0x7fffffff) am = 8 * ((int)threadIdx.x + 256 * (am >> 3)) + (am & 7);  // -> column
+    mx = amv;
+    float se = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int i = threadIdx.x + 256 * k;
+      if (i < nvec) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) se += __expf(vec_elem(r[k], j) * logit_scale - mx);
+      }
+    }
+    block_reduce4(mx, se, sx, am, amv);
+    const float lse = mx + logf(se);
+    const float xg = bf16_to_f32(x[g]) * logit_scale;
+    const float lpg = xg - lse;
+    if (threadIdx.x == 0) {
+      float sum_lp = sx - (float)V * lse;
+      float loss = eps > 0.f ? -((1.f - eps) * lpg + eps / (float)(V - 1) * (sum_lp - lpg)) : -lpg;
+      atomicAdd(stats + 0, (double)loss);
+      atomicAdd(stats + 1, am == (int)g ? 1.0 : 0.0);
+      atomicAdd(stats + 2, 1.0);
+    }
+    if (dx) {
+      __syncthreads();  // in-place use: every thread has read x[g] before any thread overwrites the row
+      const float q_other = eps > 0.f ? eps / (float)(V - 1) : 0.f;
+      const float q_gold = 1.f - eps;
+      const float gs = grad_scale * logit_scale;
+      // register position (8 * k + j) of the gold column if this thread holds it, else -1: comparing
+      // against constants keeps 8 * NV column numbers out of the registers
+      const int gv = (int)(g >> 3);
+      const int gpos = (gv & 255) == (int)threadIdx.x ? 8 * (gv >> 8) + (int)(g & 7) : -1;
+#pragma unroll
+      for (int k = 0; k < NV; ++k) {
+        const int i = threadIdx.x + 256 * k;
+        if (i < nvec) {
+          uint32_t w[4];
+#pragma unroll
+          for (int j = 0; j < 8; j += 2) {
+            const float p0 = __expf(vec_elem(r[k], j) * logit_scale - lse);
+            const float p1 = __expf(vec_elem(r[k], j + 1) * logit_scale - lse);
+            const uint32_t lo = f32_to_bf16(gs * (p0 - ((8 * k + j) == gpos ? q_gold : q_other)));
+            const uint32_t hi = f32_to_bf16(gs * (p1 - ((8 * k + j + 1) == gpos ? q_gold : q_other)));
+            w[j >> 1] = lo | (hi << 16);
+          }
+          *(u32x4_t*)(dx + 8 * (int64_t)i) = u32x4_t{w[0], w[1], w[2], w[3]};
+        }
+      }
+    }
+  }
+}
+
+// Blocks of `kernel` (256 threads, no dynamic LDS) resident on the chip at once.
+int64_t xent_resident_blocks(const void* kernel) {
+  int per_cu = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+  return (int64_t)per_cu * sk_num_cus();
+}
+
 }  // namespace
 
 extern "C" int skhip_xent_fwd_bwd(const void* logits, const int64_t* gold, void* dlogits, double* out_stats, int64_t T,
@@ -160,6 +267,25 @@ extern "C" int skhip_xent_fwd_bwd(const void* logits, const int64_t* gold, void*
   SK_CHECK_ARG(logits && gold && out_stats, "skhip_xent_fwd_bwd: null pointer");
   const int vn = dtype == SK_BF16 ? 8 : 4;
   int vec_ok = (V % vn == 0) && (ldl % vn == 0) && ((uintptr_t)logits % 16 == 0) && (!dlogits || (uintptr_t)dlogits % 16 == 0);
+  // bf16 rows that fit a block's registers: read once (SKHIP_XENT_ROWREG=0 keeps the two-sweep kernel)
+  const char* env_rr = getenv("SKHIP_XENT_ROWREG");
+  if (dtype == SK_BF16 && vec_ok && V >= 4096 && V <= 24 * 2048 && !(env_rr && env_rr[0] == '0')) {
+#define XENT_RR(NV)                                                                                              \
+  do {                                                                                                           \
+    static int64_t cap = 0;                                                                                      \
+    if (!cap) cap = xent_resident_blocks((const void*)xent_rowreg_kernel<NV>);                                   \
+    const int64_t nb = T < cap ? T : cap;                                                                        \
+    hipLaunchKernelGGL((xent_rowreg_kernel<NV>), dim3((unsigned)nb), dim3(256), 0, stream, (const bf16_t*)logits, \
+                       gold, (bf16_t*)dlogits, out_stats, T, (int)V, ldl, logit_scale, smoothing_eps, pad_id,    \
+                       grad_scale);                                                                              \
+  } while (0)
+    if (V <= 8 * 2048) XENT_RR(8);
+    else if (V <= 20 * 2048) XENT_RR(20);
+    else XENT_RR(24);
+#undef XENT_RR
+    SK_CHECK_LAUNCH("skhip_xent_fwd_bwd");
+    return SK_OK;
+  }
   int64_t blocks = T < 8192 ? T : 8192;
   if (dtype == SK_BF16)
     hipLaunchKernelGGL((xent_kernel<bf16_t>), dim3((unsigned)blocks), dim3(256), 0, stream, (const bf16_t*)logits, gold,
