@@ -26,6 +26,10 @@ SHAPES = [
     ("gen  NT T x35000x512", 0, T, V, d, torch.bfloat16),
     ("packed NT 25472x512x512", 0, 25472, d, d, torch.bfloat16),
     ("packed NT 25472x2048x512", 0, 25472, F, d, torch.bfloat16),
+    ("packed NT 25472x1536x512", 0, 25472, 3 * d, d, torch.bfloat16),
+    ("packed NT 25472x1024x512", 0, 25472, 2 * d, d, torch.bfloat16),
+    ("packed NT 25472x512x1536", 0, 25472, d, 3 * d, torch.bfloat16),
+    ("cube NT 8192x8192x8192", 0, 8192, 8192, 8192, torch.bfloat16),
     ("dgrad NN T x512 x512", 1, T, d, d, torch.bfloat16),
     ("dgrad NN T x2048x512", 1, T, F, d, torch.bfloat16),
     ("dgrad NN T x512 x2048", 1, T, d, F, torch.bfloat16),
