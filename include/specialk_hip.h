@@ -44,6 +44,9 @@ extern "C" {
 #define SK_EPI_RELU 2      /* max(., 0)                                                   */
 #define SK_EPI_RELU_MASK 4 /* multiply by (aux[m][n] > 0): backward of ReLU               */
 #define SK_EPI_ACCUM 8     /* C = result + C_old                                          */
+#define SK_EPI_RELU_BITS_OUT 16  /* with RELU: also write the sign pattern, one bit per element (bit n%16 of
+                                    uint16 word (m*N + n)/16), to aux                           */
+#define SK_EPI_RELU_MASK_BITS 32 /* as RELU_MASK, with aux holding such a bit pattern (1/16 of the bytes) */
 
 const char* skhip_version(void);
 const char* skhip_last_error(void);
@@ -59,7 +62,8 @@ int skhip_init(void);
  * (lib/transformer/Models.py:252,278) and their autograd backward.
  * in_dtype: storage of A and B; out_dtype: storage of C (bf16 inputs may write fp32, used
  * for weight gradients).  bias is always fp32 [N] (the master parameter).  aux (RELU_MASK)
- * has C's shape, ldc and in_dtype.
+ * has C's shape, ldc and in_dtype; the two *_BITS forms (bf16, NT, N % 16 == 0, 16-byte aligned
+ * operands) use a dense [M][N/16] uint16 pattern instead.
  * workspace: optional fp32 scratch for deterministic split-K (may be NULL: no split).     */
 int skhip_gemm(int layout, const void* A, const void* B, void* C, const void* bias, const void* aux,
                int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc,

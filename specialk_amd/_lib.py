@@ -12,7 +12,7 @@ import torch
 
 SK_F32, SK_BF16 = 0, 1
 GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
-EPI_BIAS, EPI_RELU, EPI_RELU_MASK, EPI_ACCUM = 1, 2, 4, 8
+EPI_BIAS, EPI_RELU, EPI_RELU_MASK, EPI_ACCUM, EPI_RELU_BITS_OUT, EPI_RELU_MASK_BITS = 1, 2, 4, 8, 16, 32
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libspecialk_hip.so")

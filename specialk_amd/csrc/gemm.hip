@@ -172,6 +172,19 @@ __device__ __forceinline__ void write_cols(const GemmParams& p, float (&v)[NC], 
 #pragma unroll
     for (int j = 0; j < NC; ++j) v[j] = a[j] > 0.f ? v[j] : 0.f;
   }
+  if constexpr (NC == 16) {  // sign patterns: one uint16 per lane and row (the host admits them only on this path)
+    if (p.epi & SK_EPI_RELU_BITS_OUT) {
+      uint32_t bits = 0;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) bits |= (v[j] > 0.f ? 1u : 0u) << j;
+      ((uint16_t*)p.aux)[((int64_t)row * p.N + col) >> 4] = (uint16_t)bits;
+    }
+    if (p.epi & SK_EPI_RELU_MASK_BITS) {
+      const uint32_t bits = ((const uint16_t*)p.aux)[((int64_t)row * p.N + col) >> 4];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) v[j] = (bits >> j) & 1u ? v[j] : 0.f;
+    }
+  }
   if (p.epi & SK_EPI_ACCUM) {
     float c[NC];
     load_cols<TOut, NC>((const TOut*)p.C + off, c);
@@ -1052,7 +1065,8 @@ extern "C" int skhip_gemm(int layout, const void* A, const void* B, void* C, con
   const char* env_cut = getenv("SKHIP_GEMM_ROWCUT");
   if (in_dtype == SK_BF16 && workspace && K >= 8192 && (layout == SK_GEMM_NT || layout == SK_GEMM_TN) && A && C &&
       M > 0 && N > 0 &&
-      M < (1ll << 31) && N < (1ll << 31) && !(env_cut && env_cut[0] == '0')) {
+      M < (1ll << 31) && N < (1ll << 31) && !(epilogue & (SK_EPI_RELU_BITS_OUT | SK_EPI_RELU_MASK_BITS)) &&
+      !(env_cut && env_cut[0] == '0')) {
     const int64_t tm = (M + 255) / 256, tn = (N + 255) / 256, ncu = sk_num_cus();
     const int64_t t256 = tm * tn, rounds = t256 / ncu, tail = t256 % ncu;
     if (rounds >= 1 && rounds < 8 && tail > 0 && 2 * tail < ncu) {
@@ -1090,6 +1104,15 @@ static int gemm_one(int layout, const void* A, const void* B, void* C, const voi
   SK_CHECK_ARG(A && B && C, "skhip_gemm: null operand");
   SK_CHECK_ARG(!(epilogue & SK_EPI_BIAS) || bias, "skhip_gemm: SK_EPI_BIAS without bias");
   SK_CHECK_ARG(!(epilogue & SK_EPI_RELU_MASK) || aux, "skhip_gemm: SK_EPI_RELU_MASK without aux");
+  constexpr int kBits = SK_EPI_RELU_BITS_OUT | SK_EPI_RELU_MASK_BITS;
+  if (epilogue & kBits) {
+    SK_CHECK_ARG(aux && (epilogue & kBits) != kBits && !(epilogue & SK_EPI_RELU_MASK),
+                 "skhip_gemm: a sign-pattern epilogue needs aux and excludes the other mask forms");
+    SK_CHECK_ARG(!(epilogue & SK_EPI_RELU_BITS_OUT) || (epilogue & SK_EPI_RELU), "skhip_gemm: SK_EPI_RELU_BITS_OUT needs SK_EPI_RELU");
+    SK_CHECK_ARG(in_dtype == SK_BF16 && layout == SK_GEMM_NT && N % 16 == 0 && (uintptr_t)aux % 2 == 0,
+                 "skhip_gemm: sign-pattern epilogues are for bf16 NT products with N %% 16 == 0");
+    workspace = nullptr;  // the pattern is written / applied in the epilogue: no split-K
+  }
   const bool a_t = layout == SK_GEMM_TN, b_t = layout != SK_GEMM_NT;
   SK_CHECK_ARG(lda >= (a_t ? M : K) && ldb >= (b_t ? N : K) && ldc >= N, "skhip_gemm: leading dimension too small");
 
@@ -1118,6 +1141,7 @@ static int gemm_one(int layout, const void* A, const void* B, void* C, const voi
             (!(epilogue & SK_EPI_RELU_MASK) || ((uintptr_t)aux % 16 == 0 && ldc % vecn == 0)) &&
             (!(epilogue & SK_EPI_BIAS) || (uintptr_t)bias % 16 == 0);
 
+  SK_CHECK_ARG(!(epilogue & kBits) || (fast && p.vec_c), "skhip_gemm: sign-pattern epilogues need 16-byte aligned operands");
   // SKHIP_GEMM_STAGED=1 selects the register-staged bf16 kernel for A/B comparisons.
   // Measured on the Transformer-base shapes (M ~ 33k, K, N in {512, 2048, 35000}): the
   // direct-to-LDS kernel wins for NT and short-K NN, the register-staged BK=64 kernel for TN

@@ -354,9 +354,16 @@ class FFNFn(torch.autograd.Function):
         T, d = x.shape
         W1c, W2c = _w2d(compute_weight(W1, x.dtype)), _w2d(compute_weight(W2, x.dtype))
         F = W1c.shape[0]
-        h = L.gemm(L.GEMM_NT, x, W1c, T, F, d, x.stride(0), d, bias=b1.detach(), epilogue=L.EPI_RELU)
+        # bf16: the first GEMM also writes the sign pattern of h, one bit per element, which is all the
+        # backward of the ReLU needs (the input-gradient GEMM then reads 1/16 of the bytes of h)
+        signs = None
+        if x.dtype == torch.bfloat16 and F % 16 == 0 and x.stride(0) % 8 == 0 and x.data_ptr() % 16 == 0:
+            signs = torch.empty((T, F // 16), dtype=torch.int16, device=x.device)
+        h = L.gemm(L.GEMM_NT, x, W1c, T, F, d, x.stride(0), d, bias=b1.detach(), aux=signs,
+                   epilogue=L.EPI_RELU | (L.EPI_RELU_BITS_OUT if signs is not None else 0))
         y = L.gemm(L.GEMM_NT, h, W2c, T, d, F, F, F, bias=b2.detach())
         ctx.save_for_backward(x, h, W1, W2)
+        ctx.signs = signs
         return y
 
     @staticmethod
@@ -367,7 +374,10 @@ class FFNFn(torch.autograd.Function):
         dres = _unalias(dres, dy)
         T, d = x.shape
         F = _as2d(W1)[0]
-        dh = _input_grad(dy, d, (W2,), T, F, x.dtype, aux=h, epilogue=L.EPI_RELU_MASK)
+        if ctx.signs is not None:
+            dh = _input_grad(dy, d, (W2,), T, F, x.dtype, aux=ctx.signs, epilogue=L.EPI_RELU_MASK_BITS)
+        else:
+            dh = _input_grad(dy, d, (W2,), T, F, x.dtype, aux=h, epilogue=L.EPI_RELU_MASK)
         dW2 = _weight_grad(dy, h, W2, T, ctx.needs_input_grad[3])
         db2 = _bias_grad(dy, T, d)
         dx = _input_grad(dh, F, (W1,), T, d, x.dtype, add_to=dres)  # accumulates into dres in place

@@ -120,6 +120,36 @@ def test_gemm_bf16_kernel_variants(L, env):
             os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
 
 
+def test_gemm_relu_sign_pattern_epilogues(L):
+    """ReLU forward that also writes one sign bit per element, and the masked backward that reads the
+    bits: same results as the forms that use the activation itself as the mask; 128- and 256-tile
+    kernels."""
+    import os
+    g = torch.Generator(device=DEV).manual_seed(23)
+    old = os.environ.get("SKHIP_GEMM_BIG")
+    try:
+        for big in ("0", "1"):
+            os.environ["SKHIP_GEMM_BIG"] = big
+            for (M, N, K) in [(300, 272, 72), (1000, 2048, 512)]:
+                x = torch.randn((M, K), device=DEV, generator=g).to(torch.bfloat16)
+                W = torch.randn((N, K), device=DEV, generator=g).to(torch.bfloat16)
+                b = torch.randn(N, device=DEV, generator=g)
+                signs = torch.zeros((M, N // 16), dtype=torch.int16, device=DEV)
+                h = L.gemm(L.GEMM_NT, x, W, M, N, K, K, K, bias=b, aux=signs, epilogue=L.EPI_RELU | L.EPI_RELU_BITS_OUT)
+                h_ref = L.gemm(L.GEMM_NT, x, W, M, N, K, K, K, bias=b, epilogue=L.EPI_RELU, split_k=False)  # the pattern forms never split K
+                assert torch.equal(h, h_ref)
+                bits = (signs.to(torch.int32) & 0xFFFF).unsqueeze(-1) >> torch.arange(16, device=DEV) & 1
+                assert torch.equal(bits.reshape(M, N).bool(), h_ref > 0)
+                dy = torch.randn((M, K), device=DEV, generator=g).to(torch.bfloat16)  # any NT product of this shape
+                got = L.gemm(L.GEMM_NT, dy, W, M, N, K, K, K, aux=signs, epilogue=L.EPI_RELU_MASK_BITS)
+                ref = L.gemm(L.GEMM_NT, dy, W, M, N, K, K, K, aux=h_ref, epilogue=L.EPI_RELU_MASK, split_k=False)
+                assert torch.equal(got, ref)
+        with pytest.raises(RuntimeError):  # N not a multiple of 16
+            L.gemm(L.GEMM_NT, x, W, 8, 24, K, K, K, aux=signs, epilogue=L.EPI_RELU | L.EPI_RELU_BITS_OUT)
+    finally:
+        os.environ.pop("SKHIP_GEMM_BIG", None) if old is None else os.environ.__setitem__("SKHIP_GEMM_BIG", old)
+
+
 def test_gemm_bf16_row_cut(L):
     """Long-K products whose 256-tiles overflow the CUs by a few tiles are computed as two row
     ranges (the second with split-K); operands, output and the ReLU-mask operand must all be
