@@ -62,7 +62,7 @@ int skhip_init(void);
  * (lib/transformer/Models.py:252,278) and their autograd backward.
  * in_dtype: storage of A and B; out_dtype: storage of C (bf16 inputs may write fp32, used
  * for weight gradients).  bias is always fp32 [N] (the master parameter).  aux (RELU_MASK)
- * has C's shape, ldc and in_dtype; the two *_BITS forms (bf16, NT, N % 16 == 0, 16-byte aligned
+ * has C's shape, ldc and in_dtype; the two *_BITS forms (bf16, NT, N % 64 == 0, 16-byte aligned
  * operands) use a dense [M][N/16] uint16 pattern instead.
  * workspace: optional fp32 scratch for deterministic split-K (may be NULL: no split).     */
 int skhip_gemm(int layout, const void* A, const void* B, void* C, const void* bias, const void* aux,

@@ -172,15 +172,22 @@ __device__ __forceinline__ void write_cols(const GemmParams& p, float (&v)[NC], 
 #pragma unroll
     for (int j = 0; j < NC; ++j) v[j] = a[j] > 0.f ? v[j] : 0.f;
   }
-  if constexpr (NC == 16) {  // sign patterns: one uint16 per lane and row (the host admits them only on this path)
+  if constexpr (NC == 16) {  // sign patterns (the host admits them only on this path)
+    // the four lanes l, l+16, l+32, l+48 of a wave hold the same row and 64 consecutive columns
+    // (every kernel's wave tile starts at a multiple of 64 columns): one 8-byte word per row
+    const int q = (col >> 4) & 3;
+    uint64_t* word = (uint64_t*)p.aux + (((int64_t)row * p.N + col) >> 6);
     if (p.epi & SK_EPI_RELU_BITS_OUT) {
       uint32_t bits = 0;
 #pragma unroll
       for (int j = 0; j < 16; ++j) bits |= (v[j] > 0.f ? 1u : 0u) << j;
-      ((uint16_t*)p.aux)[((int64_t)row * p.N + col) >> 4] = (uint16_t)bits;
+      const uint32_t other = __shfl_xor(bits, 16, 64);
+      const uint32_t pair = (q & 1) ? (other | (bits << 16)) : (bits | (other << 16));
+      const uint32_t pair2 = __shfl_xor(pair, 32, 64);
+      if (q == 0) *word = (uint64_t)pair | ((uint64_t)pair2 << 32);
     }
     if (p.epi & SK_EPI_RELU_MASK_BITS) {
-      const uint32_t bits = ((const uint16_t*)p.aux)[((int64_t)row * p.N + col) >> 4];
+      const uint32_t bits = (uint32_t)(*word >> (16 * q));
 #pragma unroll
       for (int j = 0; j < 16; ++j) v[j] = (bits >> j) & 1u ? v[j] : 0.f;
     }
@@ -1109,8 +1116,8 @@ static int gemm_one(int layout, const void* A, const void* B, void* C, const voi
     SK_CHECK_ARG(aux && (epilogue & kBits) != kBits && !(epilogue & SK_EPI_RELU_MASK),
                  "skhip_gemm: a sign-pattern epilogue needs aux and excludes the other mask forms");
     SK_CHECK_ARG(!(epilogue & SK_EPI_RELU_BITS_OUT) || (epilogue & SK_EPI_RELU), "skhip_gemm: SK_EPI_RELU_BITS_OUT needs SK_EPI_RELU");
-    SK_CHECK_ARG(in_dtype == SK_BF16 && layout == SK_GEMM_NT && N % 16 == 0 && (uintptr_t)aux % 2 == 0,
-                 "skhip_gemm: sign-pattern epilogues are for bf16 NT products with N %% 16 == 0");
+    SK_CHECK_ARG(in_dtype == SK_BF16 && layout == SK_GEMM_NT && N % 64 == 0 && (uintptr_t)aux % 8 == 0,
+                 "skhip_gemm: sign-pattern epilogues are for bf16 NT products with N %% 64 == 0");
     workspace = nullptr;  // the pattern is written / applied in the epilogue: no split-K
   }
   const bool a_t = layout == SK_GEMM_TN, b_t = layout != SK_GEMM_NT;

@@ -357,7 +357,7 @@ class FFNFn(torch.autograd.Function):
         # bf16: the first GEMM also writes the sign pattern of h, one bit per element, which is all the
         # backward of the ReLU needs (the input-gradient GEMM then reads 1/16 of the bytes of h)
         signs = None
-        if x.dtype == torch.bfloat16 and F % 16 == 0 and x.stride(0) % 8 == 0 and x.data_ptr() % 16 == 0:
+        if x.dtype == torch.bfloat16 and F % 64 == 0 and x.stride(0) % 8 == 0 and x.data_ptr() % 16 == 0:
             signs = torch.empty((T, F // 16), dtype=torch.int16, device=x.device)
         h = L.gemm(L.GEMM_NT, x, W1c, T, F, d, x.stride(0), d, bias=b1.detach(), aux=signs,
                    epilogue=L.EPI_RELU | (L.EPI_RELU_BITS_OUT if signs is not None else 0))
