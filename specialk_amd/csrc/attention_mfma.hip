@@ -110,6 +110,8 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(AttnParams p) {
 #pragma unroll
   for (int t = 0; t < D / 16; ++t) o[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
+  // 16-row groups beyond the sentence are skipped (wave-uniform branches; every wave meets every barrier)
+  const bool wave_has_q = (int)blockIdx.x * 64 + wave * 16 < Lq;
   for (int j0 = 0; j0 < Lk; j0 += OT) {
     __syncthreads();
     stage_tile<D>(Ks, K, p.ldk, j0, Lk);
@@ -119,20 +121,24 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(AttnParams p) {
       kmask[threadIdx.x] = (j >= Lk) || (p.key_pad && p.key_pad[(int64_t)b * p.Lk + j]);
     }
     __syncthreads();
+    if (!wave_has_q) continue;
+    const int nkt = min(4, (Lk - j0 + 15) >> 4);  // key tiles of this pass that hold keys
     f32x4_t sc[4];
     float mx = -INFINITY;
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) {
       sc[kt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      if (kt < nkt) {
 #pragma unroll
-      for (int s = 0; s < D / 32; ++s)
-        sc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x_rows<D>(Ks, 16 * kt, s, lane), fq[s], sc[kt], 0, 0, 0);
+        for (int s = 0; s < D / 32; ++s)
+          sc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x_rows<D>(Ks, 16 * kt, s, lane), fq[s], sc[kt], 0, 0, 0);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int jl = 16 * kt + 4 * g + r;
-        const bool msk = kmask[jl] || (p.causal && j0 + jl > q);
-        sc[kt][r] = msk ? -INFINITY : sc[kt][r] * p.scale;
-        mx = fmaxf(mx, sc[kt][r]);
+        for (int r = 0; r < 4; ++r) {
+          const int jl = 16 * kt + 4 * g + r;
+          const bool msk = kmask[jl] || (p.causal && j0 + jl > q);
+          sc[kt][r] = msk ? -INFINITY : sc[kt][r] * p.scale;
+          mx = fmaxf(mx, sc[kt][r]);
+        }
       }
     }
     const float mn = fmaxf(m, quad_max(mx));
@@ -141,13 +147,15 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(AttnParams p) {
     float rs = 0.f;
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) {
-      const uint32_t km = keep4(p, b, h, q, j0 + 16 * kt + 4 * g);
+      if (kt < nkt) {
+        const uint32_t km = keep4(p, b, h, q, j0 + 16 * kt + 4 * g);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float pr = dead ? 0.f : __expf(sc[kt][r] - mn);
-        rs += pr;
-        if (p.drop_thr) pr = (km >> r) & 1 ? pr * p.keep_scale : 0.f;
-        sc[kt][r] = pr;
+        for (int r = 0; r < 4; ++r) {
+          float pr = dead ? 0.f : __expf(sc[kt][r] - mn);
+          rs += pr;
+          if (p.drop_thr) pr = (km >> r) & 1 ? pr * p.keep_scale : 0.f;
+          sc[kt][r] = pr;
+        }
       }
     }
     l = l * alpha + quad_sum(rs);
@@ -157,7 +165,8 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(AttnParams p) {
     for (int t = 0; t < D / 16; ++t) {
       o[t] *= alpha;
       o[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x_cols<D>(Vs, 16 * t, 0, lane), y0, o[t], 0, 0, 0);
-      o[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x_cols<D>(Vs, 16 * t, 1, lane), y1, o[t], 0, 0, 0);
+      if (nkt > 2)
+        o[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x_cols<D>(Vs, 16 * t, 1, lane), y1, o[t], 0, 0, 0);
     }
   }
   if (q < Lq) {
@@ -407,92 +416,115 @@ __global__ __launch_bounds__(256) void attn_bwd_fused_mfma_kernel(AttnParams p) 
   }
   __syncthreads();
 
-  // ---- phase A: own query rows -> dQ
+  // Sentences are usually shorter than the 64-row tile: 16-row groups beyond the sentence are
+  // skipped — key tiles kt >= nkt in phase A, query halves beyond Lq in phase B, and whole waves
+  // whose own rows lie beyond it.  All branches are wave-uniform (MFMA and the transposing reads
+  // need every lane of an executing wave), and every wave still meets every barrier.
+  const int nkt = (Lk + 15) >> 4;                 // key tiles that hold keys
+  const bool two_q_halves = Lq > 32, two_k_halves = Lk > 32;
+  const bool wave_has_q = 16 * wave < Lq, wave_has_k = 16 * wave < Lk;
+
+  // ---- phase A: own query rows -> dQ; P and dS of the row for phase B
+  bf16x8_t y0, y1, z0, z1;  // packed dS (y) and P with dropout scaling (z): key tiles {0,1} and {2,3}
   {
     const int q = own;
-    bf16x8_t fq[D / 32], fdo[D / 32];
-#pragma unroll
-    for (int s = 0; s < D / 32; ++s) {
-      fq[s] = *(const bf16x8_t*)&Qs.a[q][32 * s + 8 * g];
-      fdo[s] = *(const bf16x8_t*)&dOs.a[q][32 * s + 8 * g];
-    }
-    const float lse = s_lse[q], dl = s_dl[q];
     f32x4_t ds[4], pd[4];
 #pragma unroll
-    for (int kt = 0; kt < 4; ++kt) {
-      f32x4_t sc = f32x4_t{0.f, 0.f, 0.f, 0.f}, dp = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int kt = 0; kt < 4; ++kt) ds[kt] = pd[kt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    if (wave_has_q) {
+      bf16x8_t fq[D / 32], fdo[D / 32];
 #pragma unroll
       for (int s = 0; s < D / 32; ++s) {
-        sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x_rows<D>(Ks, 16 * kt, s, lane), fq[s], sc, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x_rows<D>(Vs, 16 * kt, s, lane), fdo[s], dp, 0, 0, 0);
+        fq[s] = *(const bf16x8_t*)&Qs.a[q][32 * s + 8 * g];
+        fdo[s] = *(const bf16x8_t*)&dOs.a[q][32 * s + 8 * g];
       }
-      const uint32_t km = keep4(p, b, h, q, 16 * kt + 4 * g);
+      const float lse = s_lse[q], dl = s_dl[q];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int jl = 16 * kt + 4 * g + r;
-        const bool msk = kmask[jl] || (p.causal && jl > q) || q >= Lq;
-        const float pr = msk ? 0.f : __expf(sc[r] * p.scale - lse);
-        float dpv = dp[r], pdv = pr;
-        if (p.drop_thr) {
-          const bool kp = (km >> r) & 1;
-          dpv = kp ? dpv * p.keep_scale : 0.f;
-          pdv = kp ? pr * p.keep_scale : 0.f;
+      for (int kt = 0; kt < 4; ++kt) {
+        if (kt < nkt) {
+          f32x4_t sc = f32x4_t{0.f, 0.f, 0.f, 0.f}, dp = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int s = 0; s < D / 32; ++s) {
+            sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x_rows<D>(Ks, 16 * kt, s, lane), fq[s], sc, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x_rows<D>(Vs, 16 * kt, s, lane), fdo[s], dp, 0, 0, 0);
+          }
+          const uint32_t km = keep4(p, b, h, q, 16 * kt + 4 * g);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int jl = 16 * kt + 4 * g + r;
+            const bool msk = kmask[jl] || (p.causal && jl > q) || q >= Lq;
+            const float pr = msk ? 0.f : __expf(sc[r] * p.scale - lse);
+            float dpv = dp[r], pdv = pr;
+            if (p.drop_thr) {
+              const bool kp = (km >> r) & 1;
+              dpv = kp ? dpv * p.keep_scale : 0.f;
+              pdv = kp ? pr * p.keep_scale : 0.f;
+            }
+            pd[kt][r] = pdv;
+            ds[kt][r] = pr * (dpv - dl) * p.scale;
+          }
         }
-        pd[kt][r] = pdv;
-        ds[kt][r] = pr * (dpv - dl) * p.scale;
       }
     }
-    const bf16x8_t y0 = pack_y(ds[0], ds[1]), y1 = pack_y(ds[2], ds[3]);
-    // the transposing LDS reads need every lane active: multiply first, guard only the stores
-    f32x4_t dq[D / 16];
-#pragma unroll
-    for (int t = 0; t < D / 16; ++t) {
-      dq[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-      dq[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x_cols<D>(Ks, 16 * t, 0, lane), y0, dq[t], 0, 0, 0);
-      dq[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x_cols<D>(Ks, 16 * t, 1, lane), y1, dq[t], 0, 0, 0);
-    }
-    if (q < Lq) {
-      bf16_t* out = (bf16_t*)p.dQ + (sq.qbase + q) * p.lddq + h * D;
+    y0 = pack_y(ds[0], ds[1]); y1 = pack_y(ds[2], ds[3]);
+    z0 = pack_y(pd[0], pd[1]); z1 = pack_y(pd[2], pd[3]);
+    if (wave_has_q) {
+      f32x4_t dq[D / 16];
 #pragma unroll
       for (int t = 0; t < D / 16; ++t) {
-        uint2 w;
-        bf16_t* e = (bf16_t*)&w;
+        dq[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        dq[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x_cols<D>(Ks, 16 * t, 0, lane), y0, dq[t], 0, 0, 0);
+        if (two_k_halves)
+          dq[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x_cols<D>(Ks, 16 * t, 1, lane), y1, dq[t], 0, 0, 0);
+      }
+      if (q < Lq) {  // the multiplications above ran with every lane; only the stores are guarded
+        bf16_t* out = (bf16_t*)p.dQ + (sq.qbase + q) * p.lddq + h * D;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) e[r] = f32_to_bf16(dq[t][r]);
-        *(uint2*)(out + 16 * t + 4 * g) = w;
+        for (int t = 0; t < D / 16; ++t) {
+          uint2 w;
+          bf16_t* e = (bf16_t*)&w;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) e[r] = f32_to_bf16(dq[t][r]);
+          *(uint2*)(out + 16 * t + 4 * g) = w;
+        }
       }
     }
     // P (with the dropout scaling) and dS of the own query row replace the K and V tiles, which
     // no wave reads any more after the barrier; phase B then takes them as transposed operands
     // instead of recomputing scores, exponentials and dropout decisions for its key rows
     __syncthreads();
-#pragma unroll
-    for (int kt = 0; kt < 4; ++kt) {
-      uint2 wp, wd;
-      bf16_t* ep = (bf16_t*)&wp;
-      bf16_t* ed = (bf16_t*)&wd;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) { ep[r] = f32_to_bf16(pd[kt][r]); ed[r] = f32_to_bf16(ds[kt][r]); }
-      *(uint2*)&Ps.a[q][16 * kt + 4 * g] = wp;
-      *(uint2*)&dSs.a[q][16 * kt + 4 * g] = wd;
+    {
+      const uint4 zp0 = __builtin_bit_cast(uint4, z0), zp1 = __builtin_bit_cast(uint4, z1);
+      const uint4 yd0 = __builtin_bit_cast(uint4, y0), yd1 = __builtin_bit_cast(uint4, y1);
+      *(uint2*)&Ps.a[q][4 * g] = make_uint2(zp0.x, zp0.y);
+      *(uint2*)&Ps.a[q][16 + 4 * g] = make_uint2(zp0.z, zp0.w);
+      *(uint2*)&Ps.a[q][32 + 4 * g] = make_uint2(zp1.x, zp1.y);
+      *(uint2*)&Ps.a[q][48 + 4 * g] = make_uint2(zp1.z, zp1.w);
+      *(uint2*)&dSs.a[q][4 * g] = make_uint2(yd0.x, yd0.y);
+      *(uint2*)&dSs.a[q][16 + 4 * g] = make_uint2(yd0.z, yd0.w);
+      *(uint2*)&dSs.a[q][32 + 4 * g] = make_uint2(yd1.x, yd1.y);
+      *(uint2*)&dSs.a[q][48 + 4 * g] = make_uint2(yd1.z, yd1.w);
     }
     __syncthreads();
   }
 
   // ---- phase B: own key rows -> dK = dS^T Q, dV = P^T dO
-  {
+  if (wave_has_k) {
     const int j = own;
-    const bf16x8_t yp0 = x_cols<64>(Ps, 16 * wave, 0, lane), yp1 = x_cols<64>(Ps, 16 * wave, 1, lane);
-    const bf16x8_t ys0 = x_cols<64>(dSs, 16 * wave, 0, lane), ys1 = x_cols<64>(dSs, 16 * wave, 1, lane);
+    const bf16x8_t yp0 = x_cols<64>(Ps, 16 * wave, 0, lane), ys0 = x_cols<64>(dSs, 16 * wave, 0, lane);
+    bf16x8_t yp1 = yp0, ys1 = ys0;
+    if (two_q_halves) { yp1 = x_cols<64>(Ps, 16 * wave, 1, lane); ys1 = x_cols<64>(dSs, 16 * wave, 1, lane); }
     f32x4_t dk[D / 16], dv[D / 16];
 #pragma unroll
     for (int t = 0; t < D / 16; ++t) {
       dv[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
       dk[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
       dv[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x_cols<D>(dOs, 16 * t, 0, lane), yp0, dv[t], 0, 0, 0);
-      dv[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x_cols<D>(dOs, 16 * t, 1, lane), yp1, dv[t], 0, 0, 0);
       dk[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x_cols<D>(Qs, 16 * t, 0, lane), ys0, dk[t], 0, 0, 0);
-      dk[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x_cols<D>(Qs, 16 * t, 1, lane), ys1, dk[t], 0, 0, 0);
+      if (two_q_halves) {
+        dv[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x_cols<D>(dOs, 16 * t, 1, lane), yp1, dv[t], 0, 0, 0);
+        dk[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x_cols<D>(Qs, 16 * t, 1, lane), ys1, dk[t], 0, 0, 0);
+      }
     }
     if (j < Lk) {
       bf16_t* oK = (bf16_t*)p.dK + (sq.kbase + j) * p.lddk + h * D;
