@@ -7,7 +7,7 @@
 A "step" is one full optimiser step of the hot path on one synthetic batch per GPU:
 zero_grad, encoder-decoder forward, label-smoothed loss, backward, (N>1: bucketed RCCL SUM
 all-reduce of gradients overlapped with backward), fused Adam with the Noam schedule, dropout
-on as in the reference's training mode.  Workload (BASELINE.json configs[1]): 6+6 layers,
+on as in the reference's training mode.  Workload: 6+6 layers,
 d_model 512, 8 heads x 64, FFN 2048, vocab 35000 untied, bf16 compute with fp32 master weights,
 640 sentences per GPU with lengths U[28,50] (+SOS/EOS) = ~25k non-pad target tokens, inputs
 resident in HBM before the timed region.  Weak scaling: per-GPU batch fixed.

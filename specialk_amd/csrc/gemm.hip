@@ -5,18 +5,24 @@
 // (lib/transformer/SubLayers.py:46-48,62,73-74,81; lib/transformer/Models.py:252,278) and
 // their autograd backward (input gradient = NN layout, weight gradient = TN layout).
 //
-// Block tile 128x128, 256 threads = 4 waves in a 2x2 arrangement, each wave owns a 64x64
-// sub-tile = 4x4 MFMA tiles of 16x16 (64 fp32 accumulators per lane).  Operand tiles are
-// staged global -> registers -> LDS (double buffered, one barrier per K-step); the next
-// tile's global loads are issued before the current tile's MFMAs so that HBM latency hides
-// under compute.
+// Kernel families (namespaces below), chosen on the host per shape:
+//   b16   128x128 tile, register-staged (global -> registers -> LDS, double buffered), BK = 64:
+//         the general kernel — any alignment, all layouts;
+//   b16g  128x128 tile, direct-to-LDS loads (global_load_lds) into a three-stage ring, three
+//         blocks per CU: K-contiguous operands (NT) with short K;
+//   b16x  256x256 tile, 8 waves, four-stage direct-to-LDS ring, the two wave halves half a K-step
+//         apart: long K or tile counts that fill whole rounds of the CUs; also the grouped
+//         weight-gradient kernel (many small products in one launch);
+//   f32   128x128 tile on the exact fp32 MFMA.
+// The 128-tile kernels: 256 threads = 4 waves in a 2x2 arrangement, each wave owns a 64x64
+// sub-tile = 4x4 MFMA tiles of 16x16 (64 fp32 accumulators per lane).
 //
 // The MFMA is issued with the operands swapped (B fragment first), so the accumulator tile
 // is C^T: a lane owns ONE output row and several consecutive output columns, and the
-// epilogue (bias / ReLU / ReLU-mask / accumulate) works on 16-byte vectors and stores whole
+// epilogue (bias / ReLU / sign pattern / ReLU-mask / accumulate) works on 16-byte vectors and stores whole
 // 16-byte pieces of a row instead of 2-byte scalars.
 //
-// LDS images (bf16, BK = 64, no padding, 16 KiB per operand tile):
+// LDS images of the register-staged kernel (bf16, BK = 64, no padding, 16 KiB per operand tile):
 //   K-contiguous operand ([rows][K] in memory): [128 rows][64 k], the eight 16-byte chunks of
 //     a row XOR-swizzled with a per-row key chosen so that the ds_read_b128 fragment reads are
 //     bank-conflict free (A: key = row & 7; B, whose fragment rows are permuted so that a
