@@ -225,9 +225,13 @@ int skhip_convert(const void* src, void* dst, int64_t n, int src_dtype, int dst_
  * [R][Lmax][h*dk|h*dv] of which the first kv_len[r] (or `len` if kv_len NULL) entries are
  * valid; key_pad optional [R][Lmax].  out [R][h*dv].
  * kv_row_div >= 1: query row r reads cache row r / kv_row_div (and key_pad / kv_len row
- * r / kv_row_div), so the beams of one sentence share a single encoder-side K/V copy.       */
+ * r / kv_row_div), so the beams of one sentence share a single encoder-side K/V copy.
+ * hist_row (optional, [R][Lmax] int32): position j of query row r's history lives in cache row
+ * hist_row[r][j] (K, V and key_pad alike) — beam search re-parents hypotheses every step
+ * (Translator.py:65-101 re-orders whole tensors); re-ordering this small table instead leaves
+ * the caches in place.                                                                        */
 int skhip_decode_attn(const void* q, const void* Kc, const void* Vc, void* out,
-                      const int32_t* kv_len, const uint8_t* key_pad, int R, int n_head, int len,
+                      const int32_t* kv_len, const uint8_t* key_pad, const int32_t* hist_row, int R, int n_head, int len,
                       int Lmax, int dk, int dv, int64_t ldq, int64_t ldo, float scale,
                       int kv_row_div, int dtype, void* stream);
 

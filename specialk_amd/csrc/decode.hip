@@ -18,7 +18,8 @@ template <typename T>
 __global__ __launch_bounds__(256) void decode_attn_kernel(const T* __restrict__ q, const T* __restrict__ Kc,
                                                           const T* __restrict__ Vc, T* __restrict__ out,
                                                           const int32_t* __restrict__ kv_len,
-                                                          const uint8_t* __restrict__ key_pad, int R, int H, int len,
+                                                          const uint8_t* __restrict__ key_pad,
+                                                          const int32_t* __restrict__ hist_row, int R, int H, int len,
                                                           int Lmax, int dk, int dv, int64_t ldq, int64_t ldo, float scale,
                                                           int kv_row_div, int vec_k, int vec_v) {
   __shared__ float qs[4][128];
@@ -31,8 +32,11 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const T* __restrict__ 
   for (int c = lane; c < dk; c += 64) qs[wave][c] = Cvt<T>::to_f32(q[(int64_t)r * ldq + h * dk + c]) * scale;
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __builtin_amdgcn_wave_barrier();
-  const T* Kr = Kc + (int64_t)kr_row * Lmax * H * dk + h * dk;
-  const T* Vr = Vc + (int64_t)kr_row * Lmax * H * dv + h * dv;
+  // hist_row (optional, [R][Lmax]): the cache row that holds position j of this query row's history
+  // (beam search re-parents hypotheses every step; following the table replaces re-ordering the caches)
+  const int32_t* hr = hist_row ? hist_row + (int64_t)kr_row * Lmax : nullptr;
+  const T* Kh = Kc + h * dk;
+  const T* Vh = Vc + h * dv;
   float m = -INFINITY, l = 0.f, acc0 = 0.f, acc1 = 0.f;
   const int c0 = lane < dv ? lane : 0, c1 = lane + 64 < dv ? lane + 64 : 0;
   // P.V with 16-byte loads: lane = (row group rg, column chunk ch); a lane accumulates its VN columns
@@ -47,8 +51,9 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const T* __restrict__ 
   for (int j0 = 0; j0 < n; j0 += 64) {
     const int j = j0 + lane;
     float s = -INFINITY;
-    if (j < n && !(key_pad && key_pad[(int64_t)kr_row * Lmax + j])) {
-      const T* kr = Kr + (int64_t)j * H * dk;
+    const int64_t jrow = (int64_t)((hr && j < n) ? hr[j] : kr_row) * Lmax + j;  // cache (row, position) of key j
+    if (j < n && !(key_pad && key_pad[jrow])) {
+      const T* kr = Kh + jrow * H * dk;
       float a = 0.f;
       if (vec_k) {  // 16-byte loads of the lane's key row
         constexpr int VN = Vec16<T>::N;
@@ -76,9 +81,10 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const T* __restrict__ 
         if (i >= nch) break;
         const int t = rg + nrg * i;
         const float cf = __shfl(pr, t, 64);
+        const int64_t trow = __shfl(jrow, t, 64);
         if (j0 + t < n) {
           Vec16<T> vv;
-          vv.v = *(const decltype(vv.v)*)(Vr + (int64_t)(j0 + t) * H * dv + ch * VN);
+          vv.v = *(const decltype(vv.v)*)(Vh + trow * H * dv + ch * VN);
 #pragma unroll
           for (int e = 0; e < VN; ++e) accv[e] += cf * vv.get(e);
         }
@@ -89,7 +95,7 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const T* __restrict__ 
     const int cnt = min(64, n - j0);
     for (int t = 0; t < cnt; ++t) {
       float cf = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pr), t));
-      const T* vr = Vr + (int64_t)(j0 + t) * H * dv;
+      const T* vr = Vh + __shfl(jrow, t, 64) * H * dv;
       acc0 += cf * Cvt<T>::to_f32(vr[c0]);
       if (dv > 64) acc1 += cf * Cvt<T>::to_f32(vr[c1]);
     }
@@ -300,7 +306,8 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const char* __restrict
 }  // namespace
 
 extern "C" int skhip_decode_attn(const void* q, const void* Kc, const void* Vc, void* out, const int32_t* kv_len,
-                                 const uint8_t* key_pad, int R, int n_head, int len, int Lmax, int dk, int dv, int64_t ldq,
+                                 const uint8_t* key_pad, const int32_t* hist_row, int R, int n_head, int len, int Lmax,
+                                 int dk, int dv, int64_t ldq,
                                  int64_t ldo, float scale, int kv_row_div, int dtype, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   SK_CHECK_ARG(dtype == SK_F32 || dtype == SK_BF16, "skhip_decode_attn: bad dtype");
@@ -317,11 +324,11 @@ extern "C" int skhip_decode_attn(const void* q, const void* Kc, const void* Vc, 
                     ((uintptr_t)out % 16 == 0) && (ldo % vn == 0);
   if (dtype == SK_BF16)
     hipLaunchKernelGGL((decode_attn_kernel<bf16_t>), dim3(blocks), dim3(256), 0, stream, (const bf16_t*)q,
-                       (const bf16_t*)Kc, (const bf16_t*)Vc, (bf16_t*)out, kv_len, key_pad, R, n_head, len, Lmax, dk, dv,
+                       (const bf16_t*)Kc, (const bf16_t*)Vc, (bf16_t*)out, kv_len, key_pad, hist_row, R, n_head, len, Lmax, dk, dv,
                        ldq, ldo, scale, kv_row_div, vec_k, vec_v);
   else
     hipLaunchKernelGGL((decode_attn_kernel<float>), dim3(blocks), dim3(256), 0, stream, (const float*)q, (const float*)Kc,
-                       (const float*)Vc, (float*)out, kv_len, key_pad, R, n_head, len, Lmax, dk, dv, ldq, ldo, scale, kv_row_div, vec_k, vec_v);
+                       (const float*)Vc, (float*)out, kv_len, key_pad, hist_row, R, n_head, len, Lmax, dk, dv, ldq, ldo, scale, kv_row_div, vec_k, vec_v);
   SK_CHECK_LAUNCH("skhip_decode_attn");
   return SK_OK;
 }

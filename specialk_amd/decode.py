@@ -3,8 +3,9 @@
 Computes exactly what Translator.translate_batch of the reference computes
 (lib/transformer/Translator.py:55-226 with Beam, lib/transformer/Beam.py:14-110) but:
   * each step runs the decoder on the newest position only; keys/values of earlier positions
-    live in per-layer caches that are re-ordered by the beams' back-pointers
-    (the reference re-runs the whole prefix, O(t^2));
+    live in per-layer caches that stay in place — a small (row, position) -> cache-row table is
+    re-ordered by the beams' back-pointers instead, and the attention kernel follows it
+    (the reference re-runs the whole prefix, O(t^2), and re-orders whole tensors);
   * encoder-side keys/values are projected once per sentence and shared by its beams;
   * log-softmax, score accumulation and top-k of ALL sentences are two kernel launches
     (the reference loops over Python Beam objects and syncs with .item());
@@ -66,12 +67,15 @@ class BeamDecoder:
             L.gemm(L.GEMM_NT, enc2d, self._w(a.w_vs.weight, dt), n * Ls, H * dv, d, d, d, out=crossV[li], ldc=H * dv,
                    bias=a.w_vs.bias.detach())
 
-        # self-attention caches, double buffered for the beam re-ordering gather; the time axis is
-        # rounded up to 16 so that a row of the PAD-token bitmap can be gathered as 4-byte words
+        # self-attention caches: position t of the hypothesis that occupies row r at step t is written to
+        # cache row r and never moved; hist[r][j] names the cache row of position j of row r's history
+        # and is what the beam re-ordering permutes (double buffered).  Time axis rounded up to 16.
         Tc = (Tmax + 15) // 16 * 16
-        Kc = [torch.zeros((NL, R, Tc, H * dk), dtype=dt, device=dev) for _ in range(2)]
-        Vc = [torch.zeros((NL, R, Tc, H * dv), dtype=dt, device=dev) for _ in range(2)]
-        pad_hist = [torch.zeros((R, Tc), dtype=torch.uint8, device=dev) for _ in range(2)]
+        Kc = torch.zeros((NL, R, Tc, H * dk), dtype=dt, device=dev)
+        Vc = torch.zeros((NL, R, Tc, H * dv), dtype=dt, device=dev)
+        pad_hist = torch.zeros((R, Tc), dtype=torch.uint8, device=dev)
+        hist = [torch.zeros((R, Tc), dtype=torch.int32, device=dev) for _ in range(2)]
+        own_row = torch.arange(R, dtype=torch.int32, device=dev)
         cur = 0
 
         scores = torch.zeros((n, bm), dtype=torch.float32, device=dev)
@@ -81,7 +85,6 @@ class BeamDecoder:
         length = torch.full((n,), Tmax, dtype=torch.int32, device=dev)
         tok = torch.full((R,), Constants.SOS, dtype=torch.int64, device=dev)
         sent_base = (torch.arange(n, device=dev, dtype=torch.int32) * bm)[:, None]
-        layer_off = (torch.arange(NL, device=dev, dtype=torch.int32) * R)[:, None]
         gen_w = self._w(model.generator.weight, dt)
         V = gen_w.shape[0]
         word_emb, pos_tab = dec.tgt_word_emb.weight.detach(), dec.position_enc.weight.detach()
@@ -102,16 +105,17 @@ class BeamDecoder:
             steps = t
             pos = torch.full((R,), t, dtype=torch.int64, device=dev)
             row_pad = tok.eq(Constants.PAD).to(torch.uint8)
-            pad_hist[cur][:, t - 1] = row_pad
+            pad_hist[:, t - 1] = row_pad
+            hist[cur][:, t - 1] = own_row
             x = L.embed_fwd(tok, pos, word_emb, pos_tab, dt)
             for li, layer in enumerate(layers):
                 a = layer.slf_attn
                 q = proj(x, a.w_qs)
-                proj(x, a.w_ks, out=Kc[cur][li, :, t - 1], ldc=Tc * H * dk)
-                proj(x, a.w_vs, out=Vc[cur][li, :, t - 1], ldc=Tc * H * dv)
+                proj(x, a.w_ks, out=Kc[li, :, t - 1], ldc=Tc * H * dk)
+                proj(x, a.w_vs, out=Vc[li, :, t - 1], ldc=Tc * H * dv)
                 att = torch.empty((R, H * dv), dtype=dt, device=dev)
-                L.decode_attn(q, Kc[cur][li], Vc[cur][li], att, R, H, t, Tc, dk, dv, H * dk, H * dv, scale,
-                              key_pad=pad_hist[cur])
+                L.decode_attn(q, Kc[li], Vc[li], att, R, H, t, Tc, dk, dv, H * dk, H * dv, scale,
+                              key_pad=pad_hist, hist_row=hist[cur])
                 x = add_ln(proj(att, a.fc), x, a.layer_norm, row_pad)
                 a = layer.enc_attn
                 q = proj(x, a.w_qs)
@@ -131,16 +135,14 @@ class BeamDecoder:
             newly = (~done) & new_tok[:, 0].eq(Constants.EOS)
             length = torch.where(newly, torch.full_like(length, t), length)
             done = done | newly
-            if bool(done.all()):  # the one host sync of the step
+            # the host looks at the flag every fourth step only: a step past the end changes nothing
+            # (finished sentences keep their state) and costs less than a pipeline drain per step
+            if (t % 4 == 0 or t == Tmax) and bool(done.all()):
                 break
-            # re-order caches by back-pointer: new row (s, b) <- old row (s, prev[s, b])
-            src_row = (sent_base + prev).reshape(-1)
-            all_rows = (layer_off + src_row[None, :]).reshape(-1).contiguous()
+            # re-order the history table by back-pointer: new row (s, b) <- old row (s, prev[s, b])
+            src_row = (sent_base + prev).reshape(-1).contiguous()
             nxt = cur ^ 1
-            L.gather_rows(Kc[cur], Kc[nxt], all_rows, NL * R, t * H * dk, Tc * H * dk, Tc * H * dk)
-            L.gather_rows(Vc[cur], Vc[nxt], all_rows, NL * R, t * H * dv, Tc * H * dv, Tc * H * dv)
-            L.gather_rows(pad_hist[cur].view(torch.float32), pad_hist[nxt].view(torch.float32), src_row.contiguous(),
-                          R, Tc // 4, Tc // 4, Tc // 4)
+            L.gather_rows(hist[cur].view(torch.float32), hist[nxt].view(torch.float32), src_row, R, Tc, Tc, Tc)
             cur = nxt
             tok = new_tok.reshape(-1).to(torch.int64)
         if was_training:

@@ -527,6 +527,16 @@ def test_decode_attn(L, dtype):
     mask = keypad | (torch.arange(Lmax)[None] >= lens[:, None])
     ro, _, _ = oracle_attn(q.view(R, 1, H, dk), Kc.view(R, Lmax, H, dk), Vc.view(R, Lmax, H, dv), mask, False)
     assert rel_err(out.view(R, 1, H, dv), ro) <= tol(dtype)
+    # the same histories scattered over the cache rows (a different row permutation per position),
+    # found through the history-row table: identical output
+    perm = torch.stack([torch.randperm(R, generator=g) for _ in range(Lmax)], 1)           # (R, Lmax): row of (r, j)
+    Ks, Vs, pads = torch.zeros_like(Kc), torch.zeros_like(Vc), torch.zeros(R, Lmax, dtype=torch.uint8)
+    cols = torch.arange(Lmax)[None].expand(R, Lmax)
+    Ks[perm, cols], Vs[perm, cols], pads[perm, cols] = Kc, Vc, keypad.to(torch.uint8)
+    out2 = torch.empty_like(out)
+    L.decode_attn(q.to(DEV), Ks.to(DEV), Vs.to(DEV), out2, R, H, Lmax, Lmax, dk, dv, H * dk, H * dv, 1 / np.sqrt(dk),
+                  kv_len=lens.to(DEV), key_pad=pads.to(DEV), hist_row=perm.to(torch.int32).contiguous().to(DEV))
+    assert torch.equal(out2, out)
 
 
 @pytest.mark.parametrize("bm", [1, 3, 5, 8])
