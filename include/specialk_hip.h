@@ -229,9 +229,13 @@ int skhip_convert(const void* src, void* dst, int64_t n, int src_dtype, int dst_
  * hist_row (optional, [R][Lmax] int32): position j of query row r's history lives in cache row
  * hist_row[r][j] (K, V and key_pad alike) — beam search re-parents hypotheses every step
  * (Translator.py:65-101 re-orders whole tensors); re-ordering this small table instead leaves
- * the caches in place.                                                                        */
-int skhip_decode_attn(const void* q, const void* Kc, const void* Vc, void* out,
-                      const int32_t* kv_len, const uint8_t* key_pad, const int32_t* hist_row, int R, int n_head, int len,
+ * the caches in place.
+ * new_k / new_v (optional, [R][ld_new] rows, heads at h*dk / h*dv): key and value of the newest
+ * position len-1, taken from there and WRITTEN into the caches (row hist_row[r][len-1], or r) by
+ * this call — the cache append of the k / v projections without launches of their own.        */
+int skhip_decode_attn(const void* q, void* Kc, void* Vc, void* out,
+                      const int32_t* kv_len, const uint8_t* key_pad, const int32_t* hist_row,
+                      const void* new_k, const void* new_v, int64_t ld_new, int R, int n_head, int len,
                       int Lmax, int dk, int dv, int64_t ldq, int64_t ldo, float scale,
                       int kv_row_div, int dtype, void* stream);
 

@@ -63,7 +63,7 @@ def load():
     lib.skhip_cast_multi.argtypes = [c_p] * 3 + [c_int, c_i64, c_p]
     lib.skhip_cast2d_multi.argtypes = [c_p] * 3 + [c_int, c_i64, c_p]
     lib.skhip_convert.argtypes = [c_p, c_p, c_i64, c_int, c_int, c_p]
-    lib.skhip_decode_attn.argtypes = [c_p] * 7 + [c_int] * 6 + [c_i64, c_i64, c_f32, c_int, c_int, c_p]
+    lib.skhip_decode_attn.argtypes = [c_p] * 9 + [c_i64] + [c_int] * 6 + [c_i64, c_i64, c_f32, c_int, c_int, c_p]
     lib.skhip_beam_topk.argtypes = [c_p] * 6 + [c_int, c_int, c_i64, c_int, c_int, c_p]
     lib.skhip_gather_rows.argtypes = [c_p] * 3 + [c_i64] * 4 + [c_int, c_p]
     for name in EXPORTS:
@@ -294,10 +294,12 @@ def convert(src, dst):
 
 # --------------------------------------------------------------------------- decode
 def decode_attn(q, Kc, Vc, out, R, H, length, Lmax, dk, dv, ldq, ldo, scale, kv_len=None, key_pad=None,
-                kv_row_div=1, hist_row=None):
+                kv_row_div=1, hist_row=None, new_k=None, new_v=None, ld_new=0):
+    """new_k / new_v: rows of the newest position's key / value; the kernel appends them to the caches."""
     lib = load()
     assert hist_row is None or (hist_row.dtype == torch.int32 and hist_row.is_contiguous())
-    rc = lib.skhip_decode_attn(_ptr(q), _ptr(Kc), _ptr(Vc), _ptr(out), _ptr(kv_len), _ptr(key_pad), _ptr(hist_row), R, H, length,
+    rc = lib.skhip_decode_attn(_ptr(q), _ptr(Kc), _ptr(Vc), _ptr(out), _ptr(kv_len), _ptr(key_pad), _ptr(hist_row),
+                               _ptr(new_k), _ptr(new_v), int(ld_new), R, H, length,
                                Lmax, dk, dv, ldq, ldo, float(scale), int(kv_row_div), dcode(q.dtype), _stream())
     _check(rc, "skhip_decode_attn")
 

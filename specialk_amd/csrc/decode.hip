@@ -19,7 +19,9 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const T* __restrict__ 
                                                           const T* __restrict__ Vc, T* __restrict__ out,
                                                           const int32_t* __restrict__ kv_len,
                                                           const uint8_t* __restrict__ key_pad,
-                                                          const int32_t* __restrict__ hist_row, int R, int H, int len,
+                                                          const int32_t* __restrict__ hist_row,
+                                                          const T* __restrict__ new_k, const T* __restrict__ new_v,
+                                                          int64_t ld_new, T* Kw, T* Vw, int R, int H, int len,
                                                           int Lmax, int dk, int dv, int64_t ldq, int64_t ldo, float scale,
                                                           int kv_row_div, int vec_k, int vec_v) {
   __shared__ float qs[4][128];
@@ -52,21 +54,29 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const T* __restrict__ 
     const int j = j0 + lane;
     float s = -INFINITY;
     const int64_t jrow = (int64_t)((hr && j < n) ? hr[j] : kr_row) * Lmax + j;  // cache (row, position) of key j
-    if (j < n && !(key_pad && key_pad[jrow])) {
-      const T* kr = Kh + jrow * H * dk;
+    // new_k / new_v: key and value of the newest position (n - 1) come from the projection output
+    // and are appended to the cache here, instead of by a projection launch of their own
+    const bool fresh = new_k && j == n - 1;
+    if (j < n && (fresh || !(key_pad && key_pad[jrow]))) {
+      const T* kr = fresh ? new_k + (int64_t)r * ld_new + h * dk : Kh + jrow * H * dk;
+      T* kw = Kw + h * dk + jrow * H * dk;
       float a = 0.f;
       if (vec_k) {  // 16-byte loads of the lane's key row
         constexpr int VN = Vec16<T>::N;
         for (int c = 0; c < dk; c += VN) {
           Vec16<T> kv;
           kv.v = *(const decltype(kv.v)*)(kr + c);
+          if (fresh) *(decltype(kv.v)*)(kw + c) = kv.v;
 #pragma unroll
           for (int e = 0; e < VN; ++e) a += qs[wave][c + e] * kv.get(e);
         }
       } else {
-        for (int c = 0; c < dk; ++c) a += qs[wave][c] * Cvt<T>::to_f32(kr[c]);
+        for (int c = 0; c < dk; ++c) {
+          if (fresh) kw[c] = kr[c];
+          a += qs[wave][c] * Cvt<T>::to_f32(kr[c]);
+        }
       }
-      s = a;
+      s = (key_pad && key_pad[jrow]) ? -INFINITY : a;
     }
     float mn = fmaxf(m, wave_max(s));
     float pr = 0.f, alpha = 1.f;
@@ -84,7 +94,9 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const T* __restrict__ 
         const int64_t trow = __shfl(jrow, t, 64);
         if (j0 + t < n) {
           Vec16<T> vv;
-          vv.v = *(const decltype(vv.v)*)(Vh + trow * H * dv + ch * VN);
+          const bool fresh_v = new_v && j0 + t == n - 1;
+          vv.v = *(const decltype(vv.v)*)((fresh_v ? new_v + (int64_t)r * ld_new + h * dv : Vh + trow * H * dv) + ch * VN);
+          if (fresh_v) *(decltype(vv.v)*)(Vw + h * dv + trow * H * dv + ch * VN) = vv.v;
 #pragma unroll
           for (int e = 0; e < VN; ++e) accv[e] += cf * vv.get(e);
         }
@@ -95,7 +107,14 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const T* __restrict__ 
     const int cnt = min(64, n - j0);
     for (int t = 0; t < cnt; ++t) {
       float cf = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pr), t));
-      const T* vr = Vh + __shfl(jrow, t, 64) * H * dv;
+      const int64_t trow = __shfl(jrow, t, 64);
+      const bool fresh_v = new_v && j0 + t == n - 1;
+      const T* vr = fresh_v ? new_v + (int64_t)r * ld_new + h * dv : Vh + trow * H * dv;
+      if (fresh_v) {
+        T* vw = Vw + h * dv + trow * H * dv;
+        if (lane < dv) vw[lane] = vr[lane];
+        if (lane + 64 < dv) vw[lane + 64] = vr[lane + 64];
+      }
       acc0 += cf * Cvt<T>::to_f32(vr[c0]);
       if (dv > 64) acc1 += cf * Cvt<T>::to_f32(vr[c1]);
     }
@@ -305,9 +324,9 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const char* __restrict
 
 }  // namespace
 
-extern "C" int skhip_decode_attn(const void* q, const void* Kc, const void* Vc, void* out, const int32_t* kv_len,
-                                 const uint8_t* key_pad, const int32_t* hist_row, int R, int n_head, int len, int Lmax,
-                                 int dk, int dv, int64_t ldq,
+extern "C" int skhip_decode_attn(const void* q, void* Kc, void* Vc, void* out, const int32_t* kv_len,
+                                 const uint8_t* key_pad, const int32_t* hist_row, const void* new_k, const void* new_v,
+                                 int64_t ld_new, int R, int n_head, int len, int Lmax, int dk, int dv, int64_t ldq,
                                  int64_t ldo, float scale, int kv_row_div, int dtype, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   SK_CHECK_ARG(dtype == SK_F32 || dtype == SK_BF16, "skhip_decode_attn: bad dtype");
@@ -316,6 +335,9 @@ extern "C" int skhip_decode_attn(const void* q, const void* Kc, const void* Vc, 
   SK_CHECK_ARG(len >= 0 && len <= Lmax, "skhip_decode_attn: len=%d exceeds Lmax=%d", len, Lmax);
   if (R == 0) return SK_OK;
   SK_CHECK_ARG(q && Kc && Vc && out, "skhip_decode_attn: null pointer");
+  SK_CHECK_ARG(!new_k == !new_v, "skhip_decode_attn: new_k and new_v come together");
+  SK_CHECK_ARG(!new_k || (kv_row_div == 1 && !kv_len && len >= 1 && ld_new >= (int64_t)n_head * (dk > dv ? dk : dv)),
+               "skhip_decode_attn: appending needs one cache row per query row, a common length >= 1 and ld_new >= row width");
   unsigned blocks = (unsigned)(((int64_t)R * n_head + 3) / 4);
   const int vn = dtype == SK_BF16 ? 8 : 4;
   const int vec_k = (dk % vn == 0) && ((uintptr_t)Kc % 16 == 0);  // key rows start on 16-byte boundaries
@@ -324,11 +346,13 @@ extern "C" int skhip_decode_attn(const void* q, const void* Kc, const void* Vc, 
                     ((uintptr_t)out % 16 == 0) && (ldo % vn == 0);
   if (dtype == SK_BF16)
     hipLaunchKernelGGL((decode_attn_kernel<bf16_t>), dim3(blocks), dim3(256), 0, stream, (const bf16_t*)q,
-                       (const bf16_t*)Kc, (const bf16_t*)Vc, (bf16_t*)out, kv_len, key_pad, hist_row, R, n_head, len, Lmax, dk, dv,
+                       (const bf16_t*)Kc, (const bf16_t*)Vc, (bf16_t*)out, kv_len, key_pad, hist_row, (const bf16_t*)new_k,
+                       (const bf16_t*)new_v, ld_new, (bf16_t*)Kc, (bf16_t*)Vc, R, n_head, len, Lmax, dk, dv,
                        ldq, ldo, scale, kv_row_div, vec_k, vec_v);
   else
     hipLaunchKernelGGL((decode_attn_kernel<float>), dim3(blocks), dim3(256), 0, stream, (const float*)q, (const float*)Kc,
-                       (const float*)Vc, (float*)out, kv_len, key_pad, hist_row, R, n_head, len, Lmax, dk, dv, ldq, ldo, scale, kv_row_div, vec_k, vec_v);
+                       (const float*)Vc, (float*)out, kv_len, key_pad, hist_row, (const float*)new_k, (const float*)new_v, ld_new, (float*)Kc, (float*)Vc,
+                       R, n_head, len, Lmax, dk, dv, ldq, ldo, scale, kv_row_div, vec_k, vec_v);
   SK_CHECK_LAUNCH("skhip_decode_attn");
   return SK_OK;
 }

@@ -89,6 +89,13 @@ class BeamDecoder:
         V = gen_w.shape[0]
         word_emb, pos_tab = dec.tgt_word_emb.weight.detach(), dec.position_enc.weight.detach()
 
+        # q | k | v of the self-attention in one projection (weights stacked once per call)
+        qkv_w = [torch.cat([self._w(l.slf_attn.w_qs.weight, dt), self._w(l.slf_attn.w_ks.weight, dt),
+                            self._w(l.slf_attn.w_vs.weight, dt)], 0).contiguous() for l in layers]
+        qkv_b = [torch.cat([l.slf_attn.w_qs.bias.detach(), l.slf_attn.w_ks.bias.detach(),
+                            l.slf_attn.w_vs.bias.detach()]).float().contiguous() for l in layers]
+        nq, nk, nv = H * dk, H * dk, H * dv
+
         def proj(x, lin, out=None, ldc=None, relu=False):
             w = self._w(lin.weight, dt)
             # a (R, 512) output is a handful of tiles: split-K only pays for the long contraction of w_2,
@@ -110,12 +117,12 @@ class BeamDecoder:
             x = L.embed_fwd(tok, pos, word_emb, pos_tab, dt)
             for li, layer in enumerate(layers):
                 a = layer.slf_attn
-                q = proj(x, a.w_qs)
-                proj(x, a.w_ks, out=Kc[li, :, t - 1], ldc=Tc * H * dk)
-                proj(x, a.w_vs, out=Vc[li, :, t - 1], ldc=Tc * H * dv)
+                qkv = L.gemm(L.GEMM_NT, x, qkv_w[li], R, nq + nk + nv, d, x.stride(0), d, bias=qkv_b[li], split_k=False)
                 att = torch.empty((R, H * dv), dtype=dt, device=dev)
-                L.decode_attn(q, Kc[li], Vc[li], att, R, H, t, Tc, dk, dv, H * dk, H * dv, scale,
-                              key_pad=pad_hist, hist_row=hist[cur])
+                # the kernel takes position t-1's key / value from the projection and appends them to the caches
+                L.decode_attn(qkv, Kc[li], Vc[li], att, R, H, t, Tc, dk, dv, nq + nk + nv, H * dv, scale,
+                              key_pad=pad_hist, hist_row=hist[cur], new_k=qkv[:, nq:], new_v=qkv[:, nq + nk:],
+                              ld_new=nq + nk + nv)
                 x = add_ln(proj(att, a.fc), x, a.layer_norm, row_pad)
                 a = layer.enc_attn
                 q = proj(x, a.w_qs)

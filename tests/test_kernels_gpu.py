@@ -537,6 +537,24 @@ def test_decode_attn(L, dtype):
     L.decode_attn(q.to(DEV), Ks.to(DEV), Vs.to(DEV), out2, R, H, Lmax, Lmax, dk, dv, H * dk, H * dv, 1 / np.sqrt(dk),
                   kv_len=lens.to(DEV), key_pad=pads.to(DEV), hist_row=perm.to(torch.int32).contiguous().to(DEV))
     assert torch.equal(out2, out)
+    # append form: the newest position's key / value come from a projection buffer and are written into
+    # the caches by the kernel (common length, no kv_len)
+    n = 37
+    newkv = torch.cat([rnd((R, H * dk), dtype, g), rnd((R, 24), dtype, g), rnd((R, H * dv), dtype, g)], 1).to(DEV)
+    Kd, Vd = Ks.to(DEV).clone(), Vs.to(DEV).clone()
+    hist = perm.to(torch.int32).contiguous().to(DEV)
+    out3 = torch.empty_like(out)
+    L.decode_attn(q.to(DEV), Kd, Vd, out3, R, H, n, Lmax, dk, dv, H * dk, H * dv, 1 / np.sqrt(dk), key_pad=pads.to(DEV),
+                  hist_row=hist, new_k=newkv, new_v=newkv[:, H * dk + 24:], ld_new=newkv.shape[1])
+    Kref, Vref = Kc.clone(), Vc.clone()
+    Kref[:, n - 1], Vref[:, n - 1] = newkv[:, :H * dk].cpu(), newkv[:, H * dk + 24:].cpu()
+    m3 = keypad | (torch.arange(Lmax)[None] >= n)
+    ro3, _, _ = oracle_attn(q.view(R, 1, H, dk), Kref.view(R, Lmax, H, dk), Vref.view(R, Lmax, H, dv), m3, False)
+    assert rel_err(out3.view(R, 1, H, dv), ro3) <= tol(dtype)
+    rows = perm[:, n - 1]
+    assert torch.equal(Kd[rows, n - 1].cpu(), Kref[:, n - 1]) and torch.equal(Vd[rows, n - 1].cpu(), Vref[:, n - 1])
+    untouched = torch.ones(R, Lmax, dtype=torch.bool); untouched[rows, n - 1] = False
+    assert torch.equal(Kd.cpu()[untouched], Ks[untouched]) and torch.equal(Vd.cpu()[untouched], Vs[untouched])
 
 
 @pytest.mark.parametrize("bm", [1, 3, 5, 8])
