@@ -226,7 +226,7 @@ def main():
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    local = int(os.environ.get("SK_BENCH_DEVICE", os.environ.get("LOCAL_RANK", "0")))  # override: rehearsals on one card
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
@@ -235,7 +235,8 @@ def main():
     device = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        backend = os.environ.get("SK_BENCH_BACKEND", "nccl")  # "gloo": rehearsal of the N > 1 flow on one card
+        dist.init_process_group(backend, rank=rank, world_size=world, **({"device_id": device} if backend == "nccl" else {}))
 
     cfg = CONFIGS[args.config]
     global PACKED
@@ -273,10 +274,11 @@ def main():
     elapsed = time.perf_counter() - t0
 
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        red_dev = device if dist.get_backend() == "nccl" else "cpu"
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-        ttok = torch.tensor([tokens], dtype=torch.float64, device=device)
+        ttok = torch.tensor([tokens], dtype=torch.float64, device=red_dev)
         dist.all_reduce(ttok, op=dist.ReduceOp.SUM)
         tokens = float(ttok.item())
 
