@@ -1170,11 +1170,16 @@ static int gemm_one(int layout, const void* A, const void* B, void* C, const voi
   // SKHIP_GEMM_BIG=0/1 forces the choice (1 still requires NT + aligned operands).
   const char* env_big = getenv("SKHIP_GEMM_BIG");
   bool use_big = false;
-  if (in_dtype == SK_BF16 && fast && layout == SK_GEMM_NT && !use_staged) {
+  // A long-K NN product (generator input gradient: 25k x 512 x 35000 against the weight in its own
+  // (V, d) layout) also runs on it, and there beats the NT form against a transposed weight copy
+  // (1060 vs 1290 us: the 512-byte weight rows load in longer pieces); for K <= 2048 NT stays ahead.
+  const bool nn_long = layout == SK_GEMM_NN && K >= 8192;
+  if (in_dtype == SK_BF16 && fast && ((layout == SK_GEMM_NT && !use_staged) || (nn_long && !(env_staged && env_staged[0] == '1')))) {
     const int64_t t256 = ((M + 255) / 256) * ((N + 255) / 256), ncu = sk_num_cus();
     const int64_t rounds = (t256 + ncu - 1) / ncu;
     const double fill = (double)t256 / (double)(rounds * ncu);
     use_big = t256 >= 8 * ncu || (K >= 1024 && fill >= 0.7) || (rounds == 1 && fill >= 0.7);
+    if (use_big && nn_long) use_staged = false;
   }
   // Weight gradients (TN, long K, split-K): the 256-tile kernel when the output has enough 256-tiles
   // to keep the split count, and with it the slab traffic, moderate (measured at K = 25k: 2048x512

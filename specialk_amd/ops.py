@@ -184,6 +184,12 @@ def _input_grad(dy, ldy, Ws, T, d_in, dt, alpha=1.0, aux=None, epilogue=0, add_t
     bf16: ONE GEMM against the K-contiguous transposed copy; fp32: one exact-fp32 GEMM per weight.
     add_to: a (T, d_in) tensor the result is accumulated into (and which is returned)."""
     n_tot = sum(_as2d(w)[0] for w in Ws)
+    if dt == torch.bfloat16 and len(Ws) == 1 and n_tot >= 8192:
+        # long contraction (the generator: n = vocabulary): NN against the weight's own bf16 copy is the
+        # faster form there, and no transposed copy has to be kept up to date
+        return L.gemm(L.GEMM_NN, dy, _w2d(compute_weight(Ws[0], dt)), T, d_in, n_tot, ldy, d_in, alpha=alpha, aux=aux,
+                      epilogue=epilogue | (L.EPI_ACCUM if add_to is not None else 0), out=add_to,
+                      ldc=None if add_to is None else d_in)
     if dt == torch.bfloat16:
         return L.gemm(L.GEMM_NT, dy, derived_weight("catT", Ws), T, d_in, n_tot, ldy, n_tot, alpha=alpha, aux=aux,
                       epilogue=epilogue | (L.EPI_ACCUM if add_to is not None else 0), out=add_to,
