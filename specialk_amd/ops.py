@@ -246,7 +246,8 @@ def batched_weight_grads(on_ready=None, flush_tiles=256):
     exits — writing straight into `W.grad` (created if absent, accumulated into otherwise, so flat
     gradient buckets keep working).  A (512, 512) weight is four tiles: alone it has to be cut into
     dozens of K splits with their slab traffic to occupy the chip, in a group it is four of several
-    hundred equal work items.  on_ready(params) is called after each grouped launch with the
+    hundred equal work items.  (Thresholds of 512 or 1024 tiles measured 3 % slower end to end than 256:
+    the queued operands leave the caches before they are used.)  on_ready(params) is called after each grouped launch with the
     parameters whose gradients it wrote (a data-parallel reducer's cue; autograd hooks do not fire
     for these parameters).  Bias, LayerNorm and embedding gradients still flow through autograd."""
     global _wgrad_batch
