@@ -165,6 +165,7 @@ def _bias_grad(dy, T, N):
     """Column sums of dy, unless the LayerNorm backward that produced dy already attached them."""
     pre = getattr(dy, "_sk_colsum", None)
     if pre is not None and pre[0] == dy.data_ptr():
+        del dy._sk_colsum  # sole owner from here on: autograd can adopt the tensor as .grad instead of cloning it
         return pre[1]
     return L.colsum(dy, T, N, N)
 
