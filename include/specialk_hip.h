@@ -176,6 +176,15 @@ int skhip_embed_fwd(const int64_t* seq, const int64_t* pos, const float* word_em
 int skhip_embed_bwd(const int64_t* seq, const void* dout, float* dword_emb, int64_t T, int d,
                     int64_t n_vocab, int64_t pad_id, int dtype, void* stream);
 
+/* Row bookkeeping of a right-padded id batch seq [B][L] (the output of collate_fn,
+ * core/dataset.py:21-46) that is to be processed without its padding rows — the information the
+ * reference carries as masks (get_non_pad_mask / get_attn_key_pad_mask, lib/transformer/Models.py:21-57):
+ * lens[b] = max(#non-PAD ids of row b - trim, 0); off[B+1] = exclusive prefix sums (off[B] = n rows);
+ * idx[r] (capacity B*L, first n written) = b*L + i for packed row r = off[b] + i;
+ * facts[4] = {1 if every row is right-padded, min_b(#non-PAD - trim), max_b lens, n}.           */
+int skhip_pack_plan(const int64_t* seq, int B, int L, int trim, int64_t pad_id, int32_t* lens,
+                    int32_t* off, int64_t* idx, int64_t* facts, void* stream);
+
 /* ---- label-smoothed softmax cross-entropy, forward + backward + accuracy -------------
  * Replaces calculate_loss / performance (lib/TransformerModel.py:340-375).
  * logits [T][V] (ld = ldl) are multiplied by `logit_scale` first (x_logit_scale,

@@ -21,7 +21,7 @@ LIB_PATH = os.path.join(_HERE, "libspecialk_hip.so")
 EXPORTS = [
     "skhip_version", "skhip_last_error", "skhip_init", "skhip_gemm", "skhip_gemm_grouped_tn", "skhip_colsum", "skhip_attn_fwd",
     "skhip_attn_bwd", "skhip_attn_varlen_fwd", "skhip_attn_varlen_bwd", "skhip_add_ln_fwd", "skhip_add_ln_bwd_ws_floats", "skhip_add_ln_bwd", "skhip_embed_fwd",
-    "skhip_embed_bwd", "skhip_xent_fwd_bwd", "skhip_adam_multi", "skhip_cast_multi", "skhip_cast2d_multi", "skhip_convert",
+    "skhip_embed_bwd", "skhip_pack_plan", "skhip_xent_fwd_bwd", "skhip_adam_multi", "skhip_cast_multi", "skhip_cast2d_multi", "skhip_convert",
     "skhip_decode_attn", "skhip_beam_topk_ws_bytes", "skhip_beam_topk", "skhip_gather_rows",
 ]
 
@@ -46,6 +46,7 @@ def load():
     lib.skhip_add_ln_bwd_ws_floats.argtypes = [c_int]
     lib.skhip_beam_topk_ws_bytes.restype = c_i64
     lib.skhip_beam_topk_ws_bytes.argtypes = [c_int, c_int, c_i64]
+    lib.skhip_pack_plan.argtypes = [c_p, c_int, c_int, c_int, c_i64, c_p, c_p, c_p, c_p, c_p]
     lib.skhip_gemm_grouped_tn.argtypes = [ctypes.POINTER(c_i64), c_int, c_p, c_i64, c_p]
     lib.skhip_gemm.argtypes = [c_int, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_f32,
                                c_int, c_int, c_int, c_p, c_i64, c_p]
@@ -240,6 +241,21 @@ def embed_fwd(seq, pos, word_emb, pos_table, dtype):
                              word_emb.shape[0], pos_table.shape[0], dcode(dtype), _stream())
     _check(rc, "skhip_embed_fwd")
     return out
+
+
+def pack_plan(seq, trim, pad_id):
+    """seq (B, L) int64 on the GPU -> (lens int32 (B,), off int32 (B+1,), idx int64 (B*L,), facts int64 (4,))."""
+    lib = load()
+    B, L = seq.shape
+    dev = seq.device
+    seq = seq.contiguous()
+    lens = torch.empty(B, dtype=torch.int32, device=dev)
+    off = torch.empty(B + 1, dtype=torch.int32, device=dev)
+    idx = torch.empty(B * L, dtype=torch.int64, device=dev)
+    facts = torch.empty(4, dtype=torch.int64, device=dev)
+    _check(lib.skhip_pack_plan(_ptr(seq), B, L, int(trim), int(pad_id), _ptr(lens), _ptr(off), _ptr(idx), _ptr(facts),
+                               _stream()), "skhip_pack_plan")
+    return lens, off, idx, facts
 
 
 def embed_bwd(seq, dout, dword_emb, pad_id):

@@ -3,6 +3,7 @@
 // (lib/transformer/Models.py:117-118, 181-182).  No sqrt(d) scaling, as in the reference.
 // HBM-bound row gathers: one wave per token row, 16 bytes per lane per access.
 #include "common.h"
+#include <algorithm>
 
 namespace {
 
@@ -35,6 +36,70 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const int64_t* __restric
     float* g = dword + id * d;
     const T* s = dout + row * d;
     for (int c = lane; c < d; c += 64) atomicAdd(g + c, Cvt<T>::to_f32(s[c]));
+  }
+}
+
+// ---- row bookkeeping of a right-padded id batch held without its padding (one block)
+// lens[b] = max(count of non-PAD ids of row b - trim, 0); off = exclusive prefix sums (off[B] = n);
+// facts = {every row is right-padded, min over rows of (count - trim), max len, n}.
+__global__ __launch_bounds__(1024) void pack_lens_kernel(const int64_t* __restrict__ seq, int B, int L, int trim,
+                                                         int64_t pad_id, int32_t* __restrict__ lens,
+                                                         int32_t* __restrict__ off, int64_t* __restrict__ facts) {
+  __shared__ int s_part[1024];
+  __shared__ int s_red[3][16];
+  const int tid = threadIdx.x;
+  const int per = (B + 1023) / 1024;          // consecutive rows per thread
+  const int b0 = tid * per, b1 = min(B, b0 + per);
+  int ok = 1, lo = 0x7fffffff, hi = 0, sum = 0;
+  for (int b = b0; b < b1; ++b) {
+    const int64_t* row = seq + (int64_t)b * L;
+    int cnt = 0, last = -1;
+    for (int i = 0; i < L; ++i)
+      if (row[i] != pad_id) { ++cnt; last = i; }
+    ok &= (last + 1 == cnt);
+    const int raw = cnt - trim, ln = max(raw, 0);
+    lo = min(lo, raw); hi = max(hi, ln);
+    lens[b] = ln;
+    sum += ln;
+  }
+  // block scan of the per-thread sums (Hillis-Steele over 1024 entries)
+  s_part[tid] = sum;
+  __syncthreads();
+  for (int d = 1; d < 1024; d <<= 1) {
+    const int v = tid >= d ? s_part[tid - d] : 0;
+    __syncthreads();
+    s_part[tid] += v;
+    __syncthreads();
+  }
+  int run = s_part[tid] - sum;  // exclusive prefix of this thread's first row
+  for (int b = b0; b < b1; ++b) { off[b] = run; run += lens[b]; }
+  if (tid == 1023) off[B] = s_part[1023];
+  // reductions: ok (and), lo (min), hi (max)
+  const int lane = tid & 63, wave = tid >> 6;
+  for (int o = 32; o > 0; o >>= 1) {
+    ok &= __shfl_xor(ok, o, 64);
+    lo = min(lo, __shfl_xor(lo, o, 64));
+    hi = max(hi, __shfl_xor(hi, o, 64));
+  }
+  if (lane == 0) { s_red[0][wave] = ok; s_red[1][wave] = lo; s_red[2][wave] = hi; }
+  __syncthreads();
+  if (tid == 0) {
+    for (int w = 1; w < 16; ++w) { ok &= s_red[0][w]; lo = min(lo, s_red[1][w]); hi = max(hi, s_red[2][w]); }
+    facts[0] = ok; facts[1] = lo; facts[2] = hi; facts[3] = s_part[1023];
+  }
+}
+
+// idx[r] = b * L + (r - off[b]) for packed row r of sentence b (binary search in off)
+__global__ __launch_bounds__(256) void pack_index_kernel(const int32_t* __restrict__ off, int B, int L,
+                                                         int64_t* __restrict__ idx) {
+  const int n = off[B];
+  for (int r = blockIdx.x * 256 + threadIdx.x; r < n; r += gridDim.x * 256) {
+    int lo = 0, hi = B;  // largest b with off[b] <= r
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (off[mid] <= r) lo = mid; else hi = mid;
+    }
+    idx[r] = (int64_t)lo * L + (r - off[lo]);
   }
 }
 
@@ -76,5 +141,21 @@ extern "C" int skhip_embed_bwd(const int64_t* seq, const void* dout, float* dwor
     hipLaunchKernelGGL((embed_bwd_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, stream, seq, (const float*)dout,
                        dword_emb, T, d, pad_id);
   SK_CHECK_LAUNCH("skhip_embed_bwd");
+  return SK_OK;
+}
+
+extern "C" int skhip_pack_plan(const int64_t* seq, int B, int L, int trim, int64_t pad_id, int32_t* lens, int32_t* off,
+                               int64_t* idx, int64_t* facts, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SK_CHECK_ARG(B >= 0 && L >= 0 && trim >= 0 && (int64_t)B * L < (1ll << 31), "skhip_pack_plan: bad shape %d x %d", B, L);
+  SK_CHECK_ARG(off && facts && (B == 0 || (seq && lens && idx)), "skhip_pack_plan: null pointer");
+  hipLaunchKernelGGL(pack_lens_kernel, dim3(1), dim3(1024), 0, stream, seq, B, L, trim, pad_id, lens, off, facts);
+  SK_CHECK_LAUNCH("skhip_pack_plan(lens)");
+  if (B > 0 && L > 0) {
+    const int64_t rows = (int64_t)B * L;
+    const unsigned blocks = (unsigned)std::min<int64_t>((rows + 255) / 256, 4096);
+    hipLaunchKernelGGL(pack_index_kernel, dim3(blocks), dim3(256), 0, stream, off, B, L, idx);
+    SK_CHECK_LAUNCH("skhip_pack_plan(index)");
+  }
   return SK_OK;
 }

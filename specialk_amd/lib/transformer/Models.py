@@ -11,6 +11,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+from ... import _lib as _L
 from ... import ops
 from ...core import constants as Constants
 from .Layers import DecoderLayer, EncoderLayer
@@ -62,42 +63,32 @@ class PackPlan:
     owns rows off[b] .. off[b+1]-1 of every packed activation; idx[r] is the flat position
     b*L + i of packed row r inside the padded batch."""
 
-    def __init__(self, lens, L, max_len):
-        B = lens.shape[0]
-        ends = torch.cumsum(lens, 0)
-        n = self.n = int(max_len[1])
-        self.B, self.L, self.max_len = B, L, int(max_len[0])
-        self.off = torch.zeros(B + 1, dtype=torch.int32, device=lens.device)
-        self.off[1:] = ends
-        r = torch.arange(n, device=lens.device)
-        b = torch.searchsorted(ends, r, right=True)
-        self.idx = b * L + (r - (ends - lens)[b])
+    def __init__(self, off, idx, B, L, max_len, n):
+        self.B, self.L, self.max_len, self.n = B, L, int(max_len), int(n)
+        self.off = off
+        self.idx = idx[: self.n]
 
 
 def plan_packing(seqs, trims, check=None):
     """PackPlans for right-padded id batches `seqs` (each (B, L) on the GPU), keeping the first
-    len_b - trim tokens of every sentence.  One device -> host copy fetches what the host must
-    know (row counts, longest sentence, whether the batches really are right-padded and, if
-    `check` is given, whether ids / positions fit their tables)."""
-    lens, facts = [], []
+    len_b - trim tokens of every sentence.  Lengths, offsets and row indices are computed on the
+    device (two small launches per batch); one device -> host copy fetches what the host must know
+    (row counts, longest sentence, whether the batches really are right-padded and, if `check` is
+    given, whether ids / positions fit their tables)."""
+    parts, facts = [], []
     for seq, trim in zip(seqs, trims):
-        nz = seq.ne(Constants.PAD)
-        ln = nz.sum(1)
-        ar = torch.arange(seq.shape[1], device=seq.device)
-        facts += [(nz == (ar[None, :] < ln[:, None])).all().to(torch.int64), (ln - trim).min()]
-        ln = (ln - trim).clamp_min(0)
-        lens.append(ln)
-        facts += [ln.max(), ln.sum()]
+        _, off, idx, f = _L.pack_plan(seq, trim, Constants.PAD)
+        parts.append((off, idx))
+        facts.append(f)
     if check is not None:
-        for t, limit in check:
-            facts += [(t.max() < limit).to(torch.int64) * (t.min() >= 0).to(torch.int64)]
-    facts = torch.stack(facts).cpu().tolist()
+        facts.append(torch.stack([(t.max() < limit).to(torch.int64) * (t.min() >= 0).to(torch.int64) for t, limit in check]))
+    facts = torch.cat(facts).cpu().tolist()
     plans = []
-    for k, (seq, ln) in enumerate(zip(seqs, lens)):
+    for k, (seq, (off, idx)) in enumerate(zip(seqs, parts)):
         ok, lo, mx, n = facts[4 * k:4 * k + 4]
         if not ok or lo < 0:
             raise ValueError("packed execution needs right-padded batches whose sentences hold at least `trim` tokens")
-        plans.append(PackPlan(ln, seq.shape[1], (mx, n)))
+        plans.append(PackPlan(off, idx, seq.shape[0], seq.shape[1], mx, n))
     if check is not None and not all(facts[4 * len(seqs):]):
         raise IndexError("token id or position outside its embedding table")
     return plans

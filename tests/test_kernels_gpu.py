@@ -510,6 +510,29 @@ def test_cast_and_convert(L):
     assert torch.equal(out, b[0].float())
 
 
+def test_pack_plan(L):
+    """Lengths, offsets, row indices and the host facts of right-padded id batches, with and without a
+    trimmed last token; more sentences than the block has threads; a batch that is not right-padded."""
+    g = torch.Generator().manual_seed(12)
+    for B, Lmax, trim in ((7, 9, 0), (640, 52, 1), (2500, 6, 1), (1, 1, 0)):
+        lens = torch.randint(1 if trim == 0 else 2, Lmax + 1, (B,), generator=g) if Lmax > 1 else torch.ones(B, dtype=torch.long)
+        seq = torch.zeros(B, Lmax, dtype=torch.long)
+        for b in range(B):
+            seq[b, :lens[b]] = torch.randint(1, 50, (int(lens[b]),), generator=g)
+        ln, off, idx, facts = L.pack_plan(seq.to(DEV), trim, 0)
+        want = (lens - trim).clamp_min(0)
+        assert torch.equal(ln.cpu().long(), want)
+        assert torch.equal(off.cpu().long(), torch.cat([torch.zeros(1, dtype=torch.long), want.cumsum(0)]))
+        n = int(want.sum())
+        assert facts.cpu().tolist() == [1, int((lens - trim).min()), int(want.max()), n]
+        ref_idx = torch.cat([b * Lmax + torch.arange(int(want[b])) for b in range(B)]) if n else torch.zeros(0, dtype=torch.long)
+        assert torch.equal(idx[:n].cpu(), ref_idx)
+    bad = torch.tensor([[5, 0, 6, 0], [7, 8, 0, 0]])
+    assert L.pack_plan(bad.to(DEV), 0, 0)[3].cpu().tolist()[0] == 0
+    short = torch.tensor([[5, 0, 0], [7, 8, 9]])
+    assert L.pack_plan(short.to(DEV), 2, 0)[3].cpu().tolist()[:2] == [1, -1]
+
+
 # ------------------------------------------------------------------------------ decode
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_decode_attn(L, dtype):
