@@ -86,7 +86,7 @@ __device__ __forceinline__ float quad_sum(float v) {
 
 // ------------------------------------------------------------------------------ forward
 template <int D>
-__global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(AttnParams p) {
+__global__ __launch_bounds__(256, (D <= 64 ? 6 : 4)) void attn_fwd_mfma_kernel(AttnParams p) {
   __shared__ __attribute__((aligned(16))) Tile<D> Ks;
   __shared__ __attribute__((aligned(16))) Tile<D> Vs;
   __shared__ uint8_t kmask[OT];
