@@ -25,7 +25,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, out, packed):
+def _worker(rank, world, port, out, packed, bf16=False):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import faulthandler
@@ -40,6 +40,8 @@ def _worker(rank, world, port, out, packed):
     torch.cuda.set_device(0)
     g = load_golden("transformer_untied")
     m = load_sd(build_tiny(g, False), split_prefixed(g, "w:")).eval()
+    if bf16:
+        m = m.set_compute_dtype(torch.bfloat16)
     params = [p for p in m.parameters() if p.requires_grad]
     red = GradBucketReducer(params, bucket_mb=0.02)
     assert len(red.buckets) > 2
@@ -54,12 +56,25 @@ def _worker(rank, world, port, out, packed):
             logits = m(*shard)
             logits, gold = logits.view(-1, logits.size(2)), shard[2][:, 1:]
         loss, stats = ops.xent(logits, gold, True, unit_grad=True)
-        loss.backward()
+        if bf16:  # the trainer's form: grouped weight gradients accumulate straight into the bucket views
+            with ops.batched_weight_grads(on_ready=red.mark_ready, flush_tiles=8):
+                loss.backward()
+        else:
+            loss.backward()
         red.finish()
     tot = all_reduce_scalars(stats, "cuda")
     if rank == 0:
-        torch.save({"grads": {k: p.grad.cpu() for k, p in m.named_parameters() if p.grad is not None},
-                    "stats": tot.cpu()}, out)
+        res = {"grads": {k: p.grad.cpu() for k, p in m.named_parameters() if p.grad is not None}, "stats": tot.cpu()}
+        if bf16:  # reference for the bf16 run: the same arithmetic on the whole batch in one process, through autograd
+            m2 = load_sd(build_tiny(g, False), split_prefixed(g, "w:")).eval().set_compute_dtype(torch.bfloat16)
+            logits, gold = m2.forward_packed(*batch) if packed else (None, None)
+            if not packed:
+                logits = m2(*batch)
+                logits, gold = logits.view(-1, logits.size(2)), batch[2][:, 1:]
+            loss, _ = ops.xent(logits, gold, True, unit_grad=True)
+            loss.backward()
+            res["ref"] = {k: p.grad.cpu() for k, p in m2.named_parameters() if p.grad is not None}
+        torch.save(res, out)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -76,3 +91,16 @@ def test_two_rank_step_matches_full_batch_gradients(tmp_path, packed):
     for k, ref in split_prefixed(g, "g_ls:").items():
         a, b = got["grads"][k].double().numpy(), ref.astype(np.float64)
         assert np.abs(a - b).max() <= 1e-5 * np.abs(b).max() + 2e-6, k
+
+
+@pytest.mark.parametrize("packed", [True, False])
+def test_two_rank_step_bf16_grouped_weight_grads(tmp_path, packed):
+    """bf16 with the grouped weight-gradient launches accumulating into the reducer's bucket views:
+    the two ranks' summed gradients against a one-process whole-batch run of the same arithmetic."""
+    out = str(tmp_path / "dp.pt")
+    mp.start_processes(_worker, args=(2, _free_port(), out, packed, True), nprocs=2, join=True, start_method="forkserver")
+    got = torch.load(out)
+    assert got["grads"].keys() == got["ref"].keys()
+    for k, ref in got["ref"].items():
+        a, b = got["grads"][k].double(), ref.double()
+        assert float((a - b).norm()) <= 3e-2 * float(b.norm()) + 1e-6, k
