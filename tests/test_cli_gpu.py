@@ -122,3 +122,22 @@ def test_frozen_encoder_keeps_its_weights(tmp_path, monkeypatch):
                                                    frozen.model.decoder.state_dict().values())]
     assert any(moved)
     assert np.isfinite(ref.train_losses[0]) and np.isfinite(frozen.train_losses[0])
+
+
+def test_token_budget_batches_and_bf16_training_reduce_the_loss(tmp_path, monkeypatch):
+    """-batch_tokens (length-bucketed batches under a token budget) with -dtype bf16 — the trainer's fast
+    path: packed batches, grouped weight gradients — over a few epochs of the toy corpus: every
+    sentence is seen once per epoch and the training loss goes down."""
+    from specialk_amd.train import load_args, train_model
+    monkeypatch.chdir(tmp_path)
+    data_path = str(tmp_path / "toy.pt")
+    make_corpus(data_path, n_train=96, n_valid=16)
+    args = ["-data", data_path, "-model", "transformer", "-epochs", "6", "-batch_size", "16", "-batch_tokens", "120",
+            "-layers", "1", "-d_model", "32", "-d_word_vec", "32", "-d_inner_hid", "64", "-d_k", "8", "-d_v", "8",
+            "-n_head", "4", "-n_warmup_steps", "20", "-seed", "3", "-dropout", "0.0", "-dtype", "bf16"]
+    tm = train_model(load_args().parse_args(args))
+    sampler = tm.training_data.batch_sampler
+    seen = sorted(i for batch in sampler for i in batch)
+    assert seen == list(range(96))
+    assert len(tm.train_losses) == 6 and all(np.isfinite(tm.train_losses))
+    assert tm.train_losses[-1] < tm.train_losses[0]
