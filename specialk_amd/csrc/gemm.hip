@@ -800,7 +800,9 @@ __device__ __forceinline__ GemmParams params_of(const GroupDesc& d) {
 }
 
 __global__ __launch_bounds__(512, 1) void gemm_grouped_tn_kernel(GroupArgs g) {
-  const int bid = blockIdx.x;
+  // blocks that share an XCD (and its L2) take consecutive work items: the tiles of one problem that
+  // re-read each other's operand panels
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
   int i = 0;
   while (i + 1 < g.n && g.d[i + 1].first_block <= bid) ++i;  // uniform: a few scalar loads
   const GemmParams p = params_of(g.d[i]);
