@@ -192,10 +192,46 @@ int skhip_pack_plan(const int64_t* seq, int B, int L, int trim, int64_t pad_id, 
  * ignore_index = pad_id, reduction = "sum".
  * out_stats (double[3], caller zeroes): [0] += loss sum, [1] += n_correct, [2] += n_non_pad.
  * dlogits (may alias logits; may be NULL for evaluation) receives
- * grad_scale * logit_scale * (softmax - q) on non-pad rows and 0 on pad rows.            */
+ * grad_scale * logit_scale * (softmax - q) on non-pad rows and 0 on pad rows; when
+ * grad_scale_dev (one float in device memory, may be NULL) is given, the gradient is multiplied by
+ * it as well — the classifier loss that multiplies the reconstruction loss in
+ * train_decoder.py:471, without a host read of it.                                        */
 int skhip_xent_fwd_bwd(const void* logits, const int64_t* gold, void* dlogits, double* out_stats,
                        int64_t T, int64_t V, int64_t ldl, float logit_scale, float smoothing_eps,
-                       int64_t pad_id, float grad_scale, int dtype, void* stream);
+                       int64_t pad_id, float grad_scale, const float* grad_scale_dev, int dtype,
+                       void* stream);
+
+/* ---- style-transfer classifier path -------------------------------------------------
+ * The pieces of classifier_loss (train_decoder.py:385-424) and ConvNet.forward
+ * (classifier/onmt/CNNModels.py:48-65) that are not matrix products (those go through skhip_gemm).
+ *
+ * skhip_softmax_rows: y[r][:] = softmax(x[r][:V]) (nn.Softmax(dim=1), train_decoder.py:392,404);
+ * y may alias x.                                                                          */
+int skhip_softmax_rows(const void* x, void* y, int64_t rows, int64_t V, int64_t ldx, int64_t ldy,
+                       int dtype, void* stream);
+
+/* The classifier's input window and its convolution windows in one pass (train_decoder.py:408-418:
+ * time-major, zero-padded or trimmed to S = sequence_length steps; CNNModels.py:53-58: Conv2d with
+ * kernel (filter_size, 1) over all E channels).  emb [emb_rows][E] (ld = lde) holds the embedded
+ * probabilities of the target positions: row b*stride_b + i*stride_t of a padded batch when off is
+ * NULL (batch-major: L, 1; time-major as ConvNet.forward receives it: 1, B), or rows
+ * off[b] .. off[b+1]-1 of sentence b when the batch is stored without padding; positions past a
+ * sentence's rows and below min(L, S) then read row `pad_row` (what a zeroed decoder output embeds
+ * to), positions from L to S are zero.  cols [B*(S-filter_size+1)][filter_size*E] (ld = ldcols):
+ * cols[b*P + t][j*E + e] = step t+j, channel e of sentence b, so the convolution is
+ * cols x W^T with W[f][j*E + e] = conv1.weight[f][e][j][0].                               */
+int skhip_conv_windows(const void* emb, const int32_t* off, void* cols, int B, int L, int S,
+                       int filter_size, int E, int64_t lde, int64_t ldcols, int64_t emb_rows,
+                       int64_t pad_row, int64_t stride_b, int64_t stride_t, int dtype, void* stream);
+
+/* ReLU'd convolution outputs h [B*P][F] (ld = ldh) -> max over the P positions (MaxPool3d,
+ * CNNModels.py:36-38,60) -> Linear(F, 1) with fp32 w[F], bias[1] -> sigmoid = y[B] (fp32) ->
+ * nn.BCELoss against `target_label` (train_decoder.py:424; logarithms clamped at -100):
+ * terms[B] (fp32 scratch) and their mean in loss[0].  Dropout is the identity (eval mode,
+ * train_decoder.py:350).                                                                  */
+int skhip_cnn_head(const void* h, const float* w, const float* bias, float* y, float* terms,
+                   float* loss, int B, int P, int F, int64_t ldh, int target_label, int dtype,
+                   void* stream);
 
 /* ---- Adam ---------------------------------------------------------------------------
  * One launch over n tensors: torch.optim.Adam(betas, eps, no weight decay) as configured in

@@ -23,6 +23,7 @@ EXPORTS = [
     "skhip_attn_bwd", "skhip_attn_varlen_fwd", "skhip_attn_varlen_bwd", "skhip_add_ln_fwd", "skhip_add_ln_bwd_ws_floats", "skhip_add_ln_bwd", "skhip_embed_fwd",
     "skhip_embed_bwd", "skhip_pack_plan", "skhip_xent_fwd_bwd", "skhip_adam_multi", "skhip_cast_multi", "skhip_cast2d_multi", "skhip_convert",
     "skhip_decode_attn", "skhip_beam_topk_ws_bytes", "skhip_beam_topk", "skhip_gather_rows",
+    "skhip_softmax_rows", "skhip_conv_windows", "skhip_cnn_head",
 ]
 
 _lib = None
@@ -59,7 +60,10 @@ def load():
     lib.skhip_add_ln_bwd.argtypes = [c_p] * 13 + [c_i64, c_int, c_f32, c_u64, c_int, c_int, c_p]
     lib.skhip_embed_fwd.argtypes = [c_p] * 5 + [c_i64, c_int, c_i64, c_i64, c_int, c_p]
     lib.skhip_embed_bwd.argtypes = [c_p] * 3 + [c_i64, c_int, c_i64, c_i64, c_int, c_p]
-    lib.skhip_xent_fwd_bwd.argtypes = [c_p] * 4 + [c_i64, c_i64, c_i64, c_f32, c_f32, c_i64, c_f32, c_int, c_p]
+    lib.skhip_xent_fwd_bwd.argtypes = [c_p] * 4 + [c_i64, c_i64, c_i64, c_f32, c_f32, c_i64, c_f32, c_p, c_int, c_p]
+    lib.skhip_softmax_rows.argtypes = [c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_int, c_p]
+    lib.skhip_conv_windows.argtypes = [c_p, c_p, c_p] + [c_int] * 5 + [c_i64] * 6 + [c_int, c_p]
+    lib.skhip_cnn_head.argtypes = [c_p] * 6 + [c_int, c_int, c_int, c_i64, c_int, c_int, c_p]
     lib.skhip_adam_multi.argtypes = [c_p] * 6 + [c_int, c_i64, c_f32, c_f32, c_f32, c_f32, c_int, c_f32, c_p]
     lib.skhip_cast_multi.argtypes = [c_p] * 3 + [c_int, c_i64, c_p]
     lib.skhip_cast2d_multi.argtypes = [c_p] * 3 + [c_int, c_i64, c_p]
@@ -268,14 +272,56 @@ def embed_bwd(seq, dout, dword_emb, pad_id):
 
 
 # --------------------------------------------------------------------------- loss
-def xent_fwd_bwd(logits, gold, dlogits, stats, logit_scale, smoothing_eps, pad_id, grad_scale=1.0):
-    """logits (T,V) contiguous; stats float64[3] on device, accumulated into."""
+def xent_fwd_bwd(logits, gold, dlogits, stats, logit_scale, smoothing_eps, pad_id, grad_scale=1.0, grad_scale_dev=None):
+    """logits (T,V) contiguous; stats float64[3] on device, accumulated into; grad_scale_dev: optional
+    one-element fp32 device tensor that multiplies the gradient."""
     lib = load()
     T, V = logits.shape
+    if grad_scale_dev is not None:
+        assert grad_scale_dev.dtype == torch.float32 and grad_scale_dev.numel() == 1
     rc = lib.skhip_xent_fwd_bwd(_ptr(logits), _ptr(gold), _ptr(dlogits), _ptr(stats), T, V, logits.stride(0),
                                 float(logit_scale), float(smoothing_eps), pad_id, float(grad_scale),
-                                dcode(logits.dtype), _stream())
+                                _ptr(grad_scale_dev), dcode(logits.dtype), _stream())
     _check(rc, "skhip_xent_fwd_bwd")
+
+
+# --------------------------------------------------------------------------- style-transfer classifier path
+def softmax_rows(x, out=None):
+    """Row softmax of a 2-D tensor (rows contiguous); out may be x itself."""
+    lib = load()
+    rows, V = x.shape
+    assert x.stride(1) == 1
+    if out is None:
+        out = torch.empty((rows, V), dtype=x.dtype, device=x.device)
+    _check(lib.skhip_softmax_rows(_ptr(x), _ptr(out), rows, V, x.stride(0), out.stride(0), dcode(x.dtype), _stream()),
+           "skhip_softmax_rows")
+    return out
+
+
+def conv_windows(emb, B, L, S, filter_size, E, off=None, pad_row=0, ldcols=None, stride_b=None, stride_t=1):
+    """emb (rows, >=E) -> cols (B * (S - filter_size + 1), filter_size * E) (see the header)."""
+    lib = load()
+    P = S - filter_size + 1
+    ldcols = filter_size * E if ldcols is None else ldcols
+    cols = torch.empty((max(B * P, 0), ldcols), dtype=emb.dtype, device=emb.device)
+    if ldcols > filter_size * E:
+        cols.zero_()
+    _check(lib.skhip_conv_windows(_ptr(emb), _ptr(off), _ptr(cols), B, L, S, filter_size, E, emb.stride(0), ldcols,
+                                  emb.shape[0], int(pad_row), L if stride_b is None else stride_b, stride_t,
+                                  dcode(emb.dtype), _stream()), "skhip_conv_windows")
+    return cols
+
+
+def cnn_head(h, w, bias, B, P, F, target_label):
+    """h (B*P, >=F) ReLU'd convolution outputs -> (y (B,) fp32, loss (1,) fp32)."""
+    lib = load()
+    y = torch.empty(B, dtype=torch.float32, device=h.device)
+    terms = torch.empty(B, dtype=torch.float32, device=h.device)
+    loss = torch.empty(1, dtype=torch.float32, device=h.device)
+    assert w.dtype == torch.float32 and bias.dtype == torch.float32 and w.is_contiguous()
+    _check(lib.skhip_cnn_head(_ptr(h), _ptr(w), _ptr(bias), _ptr(y), _ptr(terms), _ptr(loss), B, P, F, h.stride(0),
+                              int(target_label), dcode(h.dtype), _stream()), "skhip_cnn_head")
+    return y, loss
 
 
 # --------------------------------------------------------------------------- optimiser

@@ -59,7 +59,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void xent_kernel(const T* __restrict__ logits, const int64_t* __restrict__ gold,
                                                    T* dlogits, double* __restrict__ stats, int64_t T_rows, int64_t V,
                                                    int64_t ldl, float logit_scale, float eps, int64_t pad_id,
-                                                   float grad_scale, int vec_ok) {
+                                                   float grad_scale, const float* __restrict__ grad_scale_dev, int vec_ok) {
   constexpr int VN = Vec16<T>::N;
   for (int64_t row = blockIdx.x; row < T_rows; row += gridDim.x) {
     const int64_t g = gold[row];
@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256) void xent_kernel(const T* __restrict__ logits,
       __syncthreads();  // in-place use: every thread has read x[g] before any thread overwrites the row
       const float q_other = eps > 0.f ? eps / (float)(V - 1) : 0.f;
       const float q_gold = 1.f - eps;
-      const float gs = grad_scale * logit_scale;
+      const float gs = grad_scale * logit_scale * (grad_scale_dev ? grad_scale_dev[0] : 1.f);
       if (vec_ok) {
         for (int64_t c = (int64_t)threadIdx.x * VN; c < V; c += 256 * VN) {
           Vec16<T> a, o;
@@ -167,7 +167,8 @@ template <int NV>
 __global__ __launch_bounds__(256, (NV <= 8 ? 4 : 3)) void xent_rowreg_kernel(const bf16_t* __restrict__ logits,
                                                           const int64_t* __restrict__ gold, bf16_t* dlogits,
                                                           double* __restrict__ stats, int64_t T_rows, int V, int64_t ldl,
-                                                          float logit_scale, float eps, int64_t pad_id, float grad_scale) {
+                                                          float logit_scale, float eps, int64_t pad_id, float grad_scale,
+                                                          const float* __restrict__ grad_scale_dev) {
   const int nvec = V >> 3;
   for (int64_t row = blockIdx.x; row < T_rows; row += gridDim.x) {
     const int64_t g = gold[row];
@@ -225,7 +226,7 @@ __global__ __launch_bounds__(256, (NV <= 8 ? 4 : 3)) void xent_rowreg_kernel(con
       __syncthreads();  // in-place use: every thread has read x[g] before any thread overwrites the row
       const float q_other = eps > 0.f ? eps / (float)(V - 1) : 0.f;
       const float q_gold = 1.f - eps;
-      const float gs = grad_scale * logit_scale;
+      const float gs = grad_scale * logit_scale * (grad_scale_dev ? grad_scale_dev[0] : 1.f);
       // register position (8 * k + j) of the gold column if this thread holds it, else -1: comparing
       // against constants keeps 8 * NV column numbers out of the registers
       const int gv = (int)(g >> 3);
@@ -261,7 +262,7 @@ int64_t xent_resident_blocks(const void* kernel) {
 
 extern "C" int skhip_xent_fwd_bwd(const void* logits, const int64_t* gold, void* dlogits, double* out_stats, int64_t T,
                                   int64_t V, int64_t ldl, float logit_scale, float smoothing_eps, int64_t pad_id,
-                                  float grad_scale, int dtype, void* stream_) {
+                                  float grad_scale, const float* grad_scale_dev, int dtype, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   SK_CHECK_ARG(dtype == SK_F32 || dtype == SK_BF16, "skhip_xent_fwd_bwd: bad dtype");
   SK_CHECK_ARG(V > 1 && V < (1ll << 31) && ldl >= V, "skhip_xent_fwd_bwd: bad V=%lld ldl=%lld", (long long)V, (long long)ldl);
@@ -280,7 +281,7 @@ extern "C" int skhip_xent_fwd_bwd(const void* logits, const int64_t* gold, void*
     const int64_t nb = T < cap ? T : cap;                                                                        \
     hipLaunchKernelGGL((xent_rowreg_kernel<NV>), dim3((unsigned)nb), dim3(256), 0, stream, (const bf16_t*)logits, \
                        gold, (bf16_t*)dlogits, out_stats, T, (int)V, ldl, logit_scale, smoothing_eps, pad_id,    \
-                       grad_scale);                                                                              \
+                       grad_scale, grad_scale_dev);                                                              \
   } while (0)
     if (V <= 8 * 2048) XENT_RR(8);
     else if (V <= 20 * 2048) XENT_RR(20);
@@ -292,10 +293,12 @@ extern "C" int skhip_xent_fwd_bwd(const void* logits, const int64_t* gold, void*
   int64_t blocks = T < 8192 ? T : 8192;
   if (dtype == SK_BF16)
     hipLaunchKernelGGL((xent_kernel<bf16_t>), dim3((unsigned)blocks), dim3(256), 0, stream, (const bf16_t*)logits, gold,
-                       (bf16_t*)dlogits, out_stats, T, V, ldl, logit_scale, smoothing_eps, pad_id, grad_scale, vec_ok);
+                       (bf16_t*)dlogits, out_stats, T, V, ldl, logit_scale, smoothing_eps, pad_id, grad_scale, grad_scale_dev,
+                       vec_ok);
   else
     hipLaunchKernelGGL((xent_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, stream, (const float*)logits, gold,
-                       (float*)dlogits, out_stats, T, V, ldl, logit_scale, smoothing_eps, pad_id, grad_scale, vec_ok);
+                       (float*)dlogits, out_stats, T, V, ldl, logit_scale, smoothing_eps, pad_id, grad_scale, grad_scale_dev,
+                       vec_ok);
   SK_CHECK_LAUNCH("skhip_xent_fwd_bwd");
   return SK_OK;
 }

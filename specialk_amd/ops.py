@@ -602,12 +602,13 @@ class XentFn(torch.autograd.Function):
     gradient; backward only scales the stored gradient."""
 
     @staticmethod
-    def forward(ctx, logits, gold, eps, logit_scale, stats, unit_grad):
+    def forward(ctx, logits, gold, eps, logit_scale, stats, unit_grad, grad_scale_dev=None):
         logits = logits.contiguous()
         ctx.unit_grad = unit_grad
         want_grad = ctx.needs_input_grad[0]
         dlogits = torch.empty_like(logits) if want_grad else None
-        L.xent_fwd_bwd(logits, gold.contiguous().view(-1), dlogits, stats, logit_scale, eps, PAD)
+        L.xent_fwd_bwd(logits, gold.contiguous().view(-1), dlogits, stats, logit_scale, eps, PAD,
+                       grad_scale_dev=grad_scale_dev)
         ctx.dlogits = dlogits
         return stats[0].to(torch.float32)
 
@@ -617,13 +618,15 @@ class XentFn(torch.autograd.Function):
         ctx.dlogits = None
         if not ctx.unit_grad:
             d = d * g.to(d.dtype)
-        return d, None, None, None, None, None
+        return d, None, None, None, None, None, None
 
 
-def xent(logits, gold, smoothing, logit_scale=1.0, unit_grad=False):
+def xent(logits, gold, smoothing, logit_scale=1.0, unit_grad=False, grad_scale_dev=None):
     """Returns (loss, stats) with stats = float64 [loss_sum, n_correct, n_non_pad] on device.
     unit_grad=True promises that the loss is differentiated directly (loss.backward()), which
-    lets backward hand out the stored gradient without a scaling pass over (T,V)."""
+    lets backward hand out the stored gradient without a scaling pass over (T,V).
+    grad_scale_dev: one-element fp32 device tensor, treated as a constant, that multiplies the gradient
+    (not the returned loss) inside the kernel — the classifier loss of train_decoder.py:471."""
     stats = torch.zeros(3, dtype=torch.float64, device=logits.device)
-    loss = XentFn.apply(logits, gold, 0.1 if smoothing else 0.0, logit_scale, stats, unit_grad)
+    loss = XentFn.apply(logits, gold, 0.1 if smoothing else 0.0, logit_scale, stats, unit_grad, grad_scale_dev)
     return loss, stats

@@ -1,0 +1,210 @@
+"""The style-transfer decoder objective (train_decoder.py / classifier ConvNet) on the HIP kernels against
+the numpy oracle and the golden vectors generated from the reference (tests/golden/style_*.npz).  GPU only.
+
+Tolerances: fp32 <= 1e-5 relative (max|a-b| / max|b|), bf16 <= 2e-2.
+"""
+from argparse import Namespace
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, split_prefixed
+from test_model_gpu import DEV, build_tiny, close, load_sd, t
+
+pytestmark = pytest.mark.gpu
+F32, BF16 = 1e-5, 2e-2
+
+
+def make_convnet(g, dtype=torch.float32, seq_length=None):
+    from specialk_amd.classifier.CNNModels import ConvNet
+    opt = Namespace(num_filters=int(g["num_filters"]), filter_size=int(g["filter_size"]),
+                    sequence_length=int(g["seq_length"]) if seq_length is None else seq_length,
+                    word_vec_size=int(g["word_vec_size"]), dropout=0.2, num_classes=2)
+    cnn = ConvNet(opt, int(g["vocab"][1]))
+    cnn.load_state_dict({k: torch.from_numpy(v) for k, v in split_prefixed(g, "cnn:").items()})
+    cnn.to(DEV).eval()
+    cnn.compute_dtype = dtype
+    cnn.refs = Namespace(tgt_label=int(g["target_label"]))
+    return cnn
+
+
+def make_class_input(g):
+    lin = torch.nn.Linear(g["class_input.weight"].shape[1], g["class_input.weight"].shape[0])
+    lin.load_state_dict({"weight": torch.from_numpy(g["class_input.weight"]), "bias": torch.from_numpy(g["class_input.bias"])})
+    return torch.nn.Sequential(lin).to(DEV)
+
+
+@pytest.mark.parametrize("dtype,V", [(torch.float32, 35000), (torch.float32, 31), (torch.bfloat16, 35000),
+                                     (torch.bfloat16, 4099), (torch.bfloat16, 8)])
+def test_softmax_rows(dtype, V):
+    from oracle.style_np import softmax_rows
+    from specialk_amd import _lib as L
+    gen = torch.Generator().manual_seed(5)
+    x = (4 * torch.randn(37, V, generator=gen)).to(dtype).to(DEV)
+    ref = softmax_rows(x.double().cpu().numpy())
+    y = L.softmax_rows(x)
+    close(y, ref, F32 if dtype == torch.float32 else 4e-3, what="softmax")
+    assert abs(y.float().sum(1) - 1).max().item() <= (1e-5 if dtype == torch.float32 else 2e-2)
+    # rows inside a wider buffer, in place
+    buf = torch.zeros(37, V + 24, dtype=dtype, device=DEV)
+    buf[:, :V] = x
+    view = buf[:, :V]
+    L.softmax_rows(view, out=view)
+    assert torch.equal(view, y) and buf[:, V:].abs().max().item() == 0
+
+
+@pytest.mark.parametrize("S", [3, 6, 11])
+def test_conv_windows_layouts(S):
+    """Padded batch-major, time-major and packed rows give the windows the reference builds by
+    transposing, zero-padding / trimming and sliding the convolution."""
+    from specialk_amd import _lib as L
+    B, Lt, E, fs = 4, 6, 8, 3
+    lens = [6, 2, 4, 1]
+    gen = torch.Generator().manual_seed(S)
+    padded = torch.randn(B, Lt, E, generator=gen)
+    pad_row = torch.randn(E, generator=gen)
+    for b, n in enumerate(lens):
+        padded[b, n:] = pad_row
+    win = torch.zeros(B, S, E)
+    win[:, :min(S, Lt)] = padded[:, :min(S, Lt)]
+    P = S - fs + 1
+    ref = torch.stack([win[:, tt:tt + fs].reshape(B, fs * E) for tt in range(P)], 1).reshape(B * P, fs * E)
+    got = L.conv_windows(padded.reshape(B * Lt, E).to(DEV), B, Lt, S, fs, E)
+    assert torch.equal(got.cpu(), ref)
+    tm = padded.transpose(0, 1).contiguous().reshape(Lt * B, E).to(DEV)
+    got = L.conv_windows(tm, B, Lt, S, fs, E, stride_b=1, stride_t=B)
+    assert torch.equal(got.cpu(), ref)
+    packed = torch.cat([padded[b, :n] for b, n in enumerate(lens)] + [pad_row[None]]).to(DEV)
+    off = torch.tensor(np.concatenate([[0], np.cumsum(lens)]), dtype=torch.int32, device=DEV)
+    got = L.conv_windows(packed, B, Lt, S, fs, E, off=off, pad_row=sum(lens))
+    assert torch.equal(got.cpu(), ref)
+    with pytest.raises(RuntimeError):
+        L.conv_windows(packed, B, Lt, S, fs, E, off=off, pad_row=sum(lens) + 1)
+    with pytest.raises(RuntimeError):
+        L.conv_windows(packed, B, Lt, 2, fs, E)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_convnet_forward_matches_oracle(dtype):
+    from oracle import style_np as S
+    g = load_golden("style_pad")
+    cnn = make_convnet(g, dtype)
+    seq, B, V = int(g["seq_length"]), 5, int(g["vocab"][1])
+    gen = torch.Generator().manual_seed(9)
+    x = torch.softmax(3 * torch.randn(seq, B, V, generator=gen), -1)
+    ref = S.convnet_fwd({k: v.astype(np.float64) for k, v in split_prefixed(g, "cnn:").items()}, x.double().numpy(),
+                        int(g["filter_size"]))
+    y = cnn(x.to(DEV))
+    assert y.shape == (B, 1)
+    close(y[:, 0], ref, F32 if dtype == torch.float32 else BF16, what="convnet")
+    with pytest.raises(ValueError):
+        cnn(x[:-1].to(DEV))
+
+
+@pytest.mark.parametrize("name", ["style_trim", "style_pad"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_classifier_loss_matches_golden(name, dtype):
+    """classifier_loss on the reference's own decoder output: padded rows and packed rows."""
+    from specialk_amd import train_decoder as TD
+    g = load_golden(name)
+    cnn, class_input = make_convnet(g, dtype), make_class_input(g)
+    dec = t(g["dec_output_0"])
+    tol = F32 if dtype == torch.float32 else BF16
+    loss = TD.classifier_loss(None, dec, cnn, class_input)
+    assert abs(loss.item() - g["losses_0"][2]) <= tol * g["losses_0"][2]
+    B, L, d = dec.shape
+    _, y = cnn.loss_from_decoder(dec.reshape(B * L, d), B, L, class_input, int(g["target_label"]))
+    close(y, g["class_outputs_0"], tol, what="class outputs")
+    lens = (g["tgt_seq_0"][:, :-1] != 0).sum(1)
+    packed = torch.cat([dec[b, :n] for b, n in enumerate(lens)])
+    off = torch.tensor(np.concatenate([[0], np.cumsum(lens)]), dtype=torch.int32, device=DEV)
+    loss_p, y_p = cnn.loss_from_decoder(packed, B, L, class_input, int(g["target_label"]), off=off)
+    close(y_p, g["class_outputs_0"], tol, what="class outputs, packed rows")
+    assert abs(loss_p.item() - g["losses_0"][2]) <= tol * g["losses_0"][2]
+
+
+def test_classifier_loss_saturated_sigmoid_clamps():
+    g = load_golden("style_pad")
+    cnn, class_input = make_convnet(g), make_class_input(g)
+    with torch.no_grad():
+        cnn.linear.bias.fill_(-1e4)
+    dec = t(g["dec_output_0"])
+    B, L, d = dec.shape
+    loss, y = cnn.loss_from_decoder(dec.reshape(B * L, d), B, L, class_input, 1)
+    assert loss.item() == 100.0 and y.abs().max().item() == 0.0
+
+
+@pytest.mark.parametrize("name", ["style_trim", "style_pad"])
+@pytest.mark.parametrize("packed", [True, False])
+def test_style_training_steps_fp32(name, packed):
+    """Three iterations of train_decoder.compute_epoch: losses, classifier outputs' loss, the gradients of
+    the first step (none for the encoder's layers) and the weights after three Adam steps."""
+    from specialk_amd import train_decoder as TD
+    from specialk_amd.lib.transformer.Optim import ScheduledOptim
+    from specialk_amd.optim import FusedAdam
+    g = load_golden(name)
+    tied = bool(g["tied"])
+    m = load_sd(build_tiny(g, tied, dropout=0.0), split_prefixed(g, "w0:"))
+    for layer in m.decoder.layer_stack:  # the fixture was generated without dropout masks
+        layer.slf_attn.attention.dropout.p = 0.0
+        layer.enc_attn.attention.dropout.p = 0.0
+    cnn, class_input = make_convnet(g), make_class_input(g)
+    so = ScheduledOptim(FusedAdam(filter(lambda x: x.requires_grad, m.parameters()), betas=(0.9, 0.98), eps=1e-09),
+                        32, int(g["n_warmup"]))
+    m.encoder.eval()
+    trainer = SimpleNamespace(model=m, optimiser=so, device=torch.device(DEV), packed=packed, tgt_bpe=None,
+                              opt=Namespace(label_smoothing=bool(g["smoothing"])))
+    batches = [[torch.from_numpy(g[f"{n}_{s}"]) for n in ("src_seq", "src_pos", "tgt_seq", "tgt_pos")] for s in range(3)]
+    # first step by hand to look at the gradients, then the epoch function for all three from fresh weights
+    l_recon, l_class, stats, _ = TD._style_batch(trainer, class_input, cnn, batches[0], trainer.opt.label_smoothing)
+    l_recon.backward()
+    ref = g["losses_0"]
+    assert abs(l_recon.item() - ref[1]) <= 2e-5 * ref[1] and abs(l_class.item() - ref[2]) <= 2e-5 * ref[2]
+    assert int(stats[1].item()) == int(ref[3])
+    named = dict(m.named_parameters())
+    for k, gref in split_prefixed(g, "g0:").items():
+        if "position_enc" in k:
+            continue
+        close(named[k].grad, gref, 5e-5, atol=1e-5, what="grad " + k)
+    assert all(p.grad is None for p in m.encoder.layer_stack.parameters())
+    assert trainer.packed == packed
+    m.zero_grad()
+    net, recon, classes, accs = TD.compute_epoch(trainer, class_input, cnn, batches)
+    for s in range(3):
+        ref = g[f"losses_{s}"]
+        assert abs(net[s] - ref[0]) <= 5e-5 * ref[0] and abs(recon[s] - ref[1]) <= 5e-5 * ref[1], (s, net[s], ref)
+        assert abs(classes[s] - ref[2]) <= 5e-5 * ref[2]
+    w0, w3 = split_prefixed(g, "w0:"), split_prefixed(g, "w3:")
+    for k, p in m.state_dict().items():
+        if k.endswith("w_ks.bias"):
+            continue  # zero true gradient; Adam amplifies rounding noise
+        got, refw = p.double().cpu().numpy(), w3[k].astype(np.float64)
+        upd = np.linalg.norm(refw - w0[k])
+        if upd == 0:
+            assert np.array_equal(got, refw), k  # encoder layers: untouched
+            continue
+        assert np.linalg.norm(got - refw) <= 5e-4 * upd, (k, np.linalg.norm(got - refw) / upd)
+    # validation branch: no update, same kind of lists
+    before = {k: v.clone() for k, v in m.state_dict().items()}
+    with torch.no_grad():
+        out = TD.compute_epoch(trainer, class_input, cnn, batches[:1], validation=True)
+    assert len(out[0]) == 1 and all(torch.equal(v, before[k]) for k, v in m.state_dict().items())
+
+
+def test_style_step_bf16_close_to_fp32():
+    from specialk_amd import train_decoder as TD
+    g = load_golden("style_pad")
+    res = {}
+    for dtype in (torch.float32, torch.bfloat16):
+        m = load_sd(build_tiny(g, True, dropout=0.0), split_prefixed(g, "w0:")).set_compute_dtype(dtype).eval()
+        cnn, class_input = make_convnet(g, dtype), make_class_input(g)
+        trainer = SimpleNamespace(model=m, device=torch.device(DEV), packed=True, opt=Namespace(label_smoothing=False))
+        batch = [torch.from_numpy(g[f"{n}_0"]) for n in ("src_seq", "src_pos", "tgt_seq", "tgt_pos")]
+        l_recon, l_class, _, _ = TD._style_batch(trainer, class_input, cnn, batch, False)
+        l_recon.backward()
+        res[dtype] = (l_recon.item(), l_class.item(), m.generator.weight.grad.clone())
+    a, b = res[torch.float32], res[torch.bfloat16]
+    assert abs(a[0] - b[0]) <= BF16 * a[0] and abs(a[1] - b[1]) <= BF16 * a[1]
+    assert (a[2] - b[2]).norm() <= 0.15 * a[2].norm()
