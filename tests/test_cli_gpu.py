@@ -141,3 +141,40 @@ def test_token_budget_batches_and_bf16_training_reduce_the_loss(tmp_path, monkey
     assert seen == list(range(96))
     assert len(tm.train_losses) == 6 and all(np.isfinite(tm.train_losses))
     assert tm.train_losses[-1] < tm.train_losses[0]
+
+
+def test_train_decoder_cli_fine_tunes_decoder_only(tmp_path, monkeypatch):
+    """train -> train_decoder on the saved checkpoints with a classifier checkpoint: the decoder
+    checkpoints appear in the reference's format and every decoder weight has moved."""
+    from specialk_amd import train_decoder as TD
+    from specialk_amd.classifier.CNNModels import ConvNet
+    from specialk_amd.train import load_args, train_model
+    monkeypatch.chdir(tmp_path)
+    data_path = str(tmp_path / "toy.pt")
+    make_corpus(data_path, n_train=48, n_valid=16)
+    train_model(load_args().parse_args([
+        "-data", data_path, "-model", "transformer", "-epochs", "1", "-batch_size", "8", "-layers", "2",
+        "-d_model", "32", "-d_word_vec", "32", "-d_inner_hid", "64", "-d_k", "8", "-d_v", "8", "-n_head", "4",
+        "-n_warmup_steps", "10", "-save_model", "-directory_name", "run", "-seed", "5"]))
+    run = tmp_path / "models" / "run"
+    torch.manual_seed(3)
+    class_opt = Namespace(num_filters=6, filter_size=3, sequence_length=12, word_vec_size=8, dropout=0.2, num_classes=2)
+    cnn = ConvNet(class_opt, len(WORDS))
+    torch.save({"model": cnn.state_dict(), "opt": class_opt}, tmp_path / "cnn.pt")
+    dec0 = torch.load(run / "decoder_epoch_1.chkpt", weights_only=False)["model"]
+    TD.main(["-data", data_path, "-checkpoint_encoder", str(run / "encoder_epoch_1.chkpt"),
+             "-checkpoint_decoder", str(run / "decoder_epoch_1.chkpt"), "-epochs", "2", "-batch_size", "8",
+             "-classifier_model", str(tmp_path / "cnn.pt"), "-label0", "a", "-label1", "b", "-label_target", "b",
+             "-label_smoothing", "-seed", "9"])
+    for ep in (1, 2):
+        assert (run / f"decoder_b_epoch_{ep}.chkpt").is_file()
+    out = torch.load(run / "decoder_b_epoch_2.chkpt", weights_only=False)
+    assert set(out) == {"type", "model", "generator", "epoch", "settings", "vocab"} and out["epoch"] == 2
+    moved = [not torch.equal(v.cpu(), dec0[k].cpu()) for k, v in out["model"].items() if "position_enc" not in k]
+    assert all(moved)
+    assert all(torch.isfinite(v).all() for v in out["model"].values())
+    # a classifier file that pickles anything but tensors and the options is refused by the loader
+    torch.save({"model": cnn.state_dict(), "opt": class_opt, "optim": ConvNet}, tmp_path / "bad.pt")
+    with pytest.raises(RuntimeError, match="classifier checkpoint"):
+        TD.load_classifier(Namespace(classifier_model=str(tmp_path / "bad.pt"), label0="a", label1="b", label_target="b",
+                                     batch_size=8), Namespace(opt=Namespace(max_token_seq_len=12, tgt_vocab_size=len(WORDS))))
