@@ -3,8 +3,11 @@ choice, run directory, CSV logs, dataset / test-data loaders, id -> text decodin
 
 Outside the accelerated path (host-side plumbing only).  Differences from the reference:
   * the device is always a GPU (this package has no CPU path); `-cuda_device` selects it;
-  * the Telegram notifier and the BPE vocabulary class are optional: they are imported on use,
-    and a clear error is raised when the supporting package is not installed;
+  * the Telegram notifier is optional: it is imported on use, and a clear error is raised when its
+    package is not installed; the BPE vocabulary class is this package's own core.bpe.Encoder;
+  * BPE test sentences that encode to more than max_token_seq_len - 2 ids lose words from the end until
+    they fit — what the reference's `reclip` (preprocess.py:141-157) sets out to do; as written it hands
+    `transform` a string and so keeps the encoding of the sentence's first character only;
   * under torch.distributed only rank 0 creates directories and writes logs / checkpoints.
 """
 import atexit
@@ -16,6 +19,7 @@ import torch
 import torch.utils.data
 
 from ..core import constants
+from ..core.bpe import Encoder as BPE
 from ..core.dataset import TokenBudgetBatchSampler, TranslationDataset, collate_fn, paired_collate_fn
 
 
@@ -34,6 +38,21 @@ def load_text_file(filepath, case_sensitive=True, max_seq=None):
             line = line if case_sensitive else line.lower()
             sequences.append(line.strip().split())
     return sequences
+
+
+def load_text_lines(filepath, case_sensitive=True):
+    """One raw sentence per line (the form a BPE vocabulary tokenizes itself)."""
+    with open(filepath) as f:
+        return [(line if case_sensitive else line.lower()).strip() for line in f]
+
+
+def reclip(ref_seq, bpe_seq, enc, max_len):
+    """Ids of the longest prefix (in whitespace words) of `ref_seq` whose encoding has at most max_len ids."""
+    words = ref_seq.split()
+    while len(bpe_seq) > max_len and words:
+        words.pop()
+        bpe_seq = next(iter(enc.transform([" ".join(words)])))
+    return bpe_seq[:max_len]
 
 
 def seq2idx(sequences, w2i):
@@ -134,6 +153,9 @@ class NMTModel:
         data = torch.load(self.opt.data, weights_only=False)
         self.dataset_settings = data["settings"]
         self.opt.max_token_seq_len = data["settings"].max_token_seq_len
+        if "byte_pairs" in data["dict"]["src"] and "__sow" in data["dict"]["src"]["byte_pairs"]:
+            self.src_bpe = BPE.from_dict(data["dict"]["src"])  # lib/nmtModel.py:219-223
+            self.tgt_bpe = BPE.from_dict(data["dict"]["tgt"])
         self.training_data, self.validation_data = self.init_dataloaders(data, self.opt)
         self.opt.src_vocab_size = self.training_data.dataset.src_vocab_size
         self.opt.tgt_vocab_size = self.training_data.dataset.tgt_vocab_size
@@ -175,9 +197,16 @@ class NMTModel:
         if override and override > 0:
             settings.max_token_seq_len = override
             self.change_max_seq_len(override + 5)
-        if is_bpe:
-            raise NotImplementedError(
-                "BPE test data needs the reference's core.bpe.Encoder (toolz / nltk), which is outside this package")
+        if is_bpe:  # lib/nmtModel.py:267-305
+            bpe_src, decoder = BPE.from_dict(data["dict"]["src"]), BPE.from_dict(data["dict"]["tgt"])
+            lines = load_text_lines(test_datapath, getattr(settings, "case_sensitive", True))
+            insts = [[constants.SOS] + reclip(raw, enc, bpe_src, settings.max_token_seq_len - 2) + [constants.EOS]
+                     for raw, enc in zip(lines, bpe_src.transform(lines))]
+            src_w2i, _ = self._flatten_vocab(data["dict"]["src"])
+            tgt_w2i, _ = self._flatten_vocab(data["dict"]["tgt"])
+            ds = TranslationDataset(src_word2idx=src_w2i, tgt_word2idx=tgt_w2i, src_insts=insts)
+            loader = torch.utils.data.DataLoader(ds, num_workers=0, batch_size=self.opt.batch_size, collate_fn=collate_fn)
+            return loader, settings.max_token_seq_len, is_bpe, decoder
         sents = load_text_file(test_datapath, getattr(settings, "case_sensitive", True))
         insts = seq2idx(sents, data["dict"]["src"])
         insts = [[constants.SOS] + s[: settings.max_word_seq_len] + [constants.EOS] for s in insts]

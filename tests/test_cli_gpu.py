@@ -178,3 +178,41 @@ def test_train_decoder_cli_fine_tunes_decoder_only(tmp_path, monkeypatch):
     with pytest.raises(RuntimeError, match="classifier checkpoint"):
         TD.load_classifier(Namespace(classifier_model=str(tmp_path / "bad.pt"), label0="a", label1="b", label_target="b",
                                      batch_size=8), Namespace(opt=Namespace(max_token_seq_len=12, tgt_vocab_size=len(WORDS))))
+
+
+def test_bpe_dataset_trains_and_translates_text(tmp_path, monkeypatch):
+    """A dataset in the reference's BPE format (dict = Encoder.vocabs_to_dict()): training picks up the
+    vocabularies, translate.py encodes raw text with the source vocabulary and writes decoded words."""
+    from specialk_amd import translate as translate_cli
+    from specialk_amd.core.bpe import Encoder
+    from specialk_amd.lib.nmtModel import NMTModel
+    from specialk_amd.train import load_args, train_model
+    monkeypatch.chdir(tmp_path)
+    rng = np.random.default_rng(4)
+    words = ["alpha", "beta", "gamma", "delta", "epsilon", "zeta", "eta", "theta", "iota", "kappa", "lambda", "mu"]
+    sents = [" ".join(rng.choice(words, size=int(rng.integers(2, 6)))) for _ in range(80)]
+    enc = Encoder(vocab_size=48, pct_bpe=0.75, ngram_min=1, ngram_max=2)
+    enc.fit(sents)
+    ids = [[2] + s + [3] for s in enc.transform(sents)]
+    assert max(len(s) for s in ids) <= 40
+    data = {"settings": Namespace(max_token_seq_len=40, max_word_seq_len=38, format="bpe", case_sensitive=True),
+            "dict": {"src": enc.vocabs_to_dict(), "tgt": enc.vocabs_to_dict()},
+            "train": {"src": ids[:64], "tgt": ids[:64]}, "valid": {"src": ids[64:], "tgt": ids[64:]}}
+    data_path = str(tmp_path / "bpe.pt")
+    torch.save(data, data_path)
+    model = train_model(load_args().parse_args([
+        "-data", data_path, "-model", "transformer", "-epochs", "1", "-batch_size", "16", "-layers", "1",
+        "-d_model", "32", "-d_word_vec", "32", "-d_inner_hid", "64", "-d_k", "8", "-d_v", "8", "-n_head", "4",
+        "-n_warmup_steps", "10", "-save_model", "-directory_name", "bpe", "-seed", "3"]))
+    assert model.tgt_bpe is not None and model.src_bpe is not None
+    run = tmp_path / "models" / "bpe"
+    src_txt = tmp_path / "in.txt"
+    src_txt.write_text("alpha beta gamma\nkappa omega mu\n" + " ".join(["epsilon"] * 30) + "\n")
+    out_txt = tmp_path / "out.txt"
+    hyps = translate_cli.main([
+        "-model", "transformer", "-src", str(src_txt), "-vocab", data_path, "-output", str(out_txt),
+        "-checkpoint_encoder", str(run / "encoder_epoch_1.chkpt"), "-checkpoint_decoder", str(run / "decoder_epoch_1.chkpt"),
+        "-batch_size", "2", "-beam_size", "2", "-n_best", "1"])
+    lines = out_txt.read_text().split("\n")[:-1]
+    assert len(hyps) == 3 and len(lines) == 3
+    assert lines == NMTModel.translate_decode_bpe(hyps, enc)
