@@ -147,6 +147,20 @@ def gemm_roofline(m, opt, batch, steps):
     ms = sum(e0.elapsed_time(e1) for e0, e1, _, _ in records)
     flops = sum(f for _, _, f, _ in records)
     n = len(records)
+    # HBM-side bytes per GEMM launch from the committed counter passes of this same command (rocprofv3 --pmc
+    # FETCH_SIZE and --pmc WRITE_SIZE, separate runs; tools/pmc_hbm_traffic.py): counters cannot be read in-process
+    traffic, traffic_src = None, None
+    pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_hbm_traffic.json")
+    if os.path.exists(pmc):
+        with open(pmc) as f:
+            traffic = round(json.load(f)["hbm_bytes_per_launch"])
+        traffic_src = "profiles/r01_pmc_hbm_traffic.json (bytes per launch, cfg2)"
+    out = _roofline_dict(flops, ms, n, steps)
+    out["traffic"], out["traffic_source"] = traffic, traffic_src
+    return out
+
+
+def _roofline_dict(flops, ms, n, steps):
     return dict(bound="mfma", achieved=round(flops / (ms * 1e-3) / 1e12, 2), peak=MFMA_BF16_PEAK_TFLOPS,
                 unit="TFLOP/s", frac=round(flops / (ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4), traffic=None,
                 kernel="b16x/b16g/b16::gemm_kernel + b16x::gemm_grouped_tn_kernel (bf16 MFMA GEMMs, all layouts)", launches_per_step=n // steps,
@@ -298,6 +312,8 @@ def main():
     if rank == 0 and world == 1:
         if not args.no_roofline and args.dtype == "bf16":
             out["roofline"] = gemm_roofline(m, opt, batches[0], 3)
+            if args.config != "cfg2" or args.padded:  # the counter passes were taken on the default workload
+                out["roofline"]["traffic"] = out["roofline"]["traffic_source"] = None
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg)
     if rank == 0:
