@@ -1144,6 +1144,9 @@ static int gemm_one(int layout, const void* A, const void* B, void* C, const voi
   // (measured on 8192^3: 870 -> 1317 TFLOP/s with the 256-tile kernel); with a short K the
   // row-major order is better (its concurrent tiles write adjacent pieces of the same C rows).
   p.group = (K >= 4096 && N >= 2048 && M >= 2048) ? 8 : 1;
+  // a very wide output with a short K (generator: 25 k x 35 000 x 512): pairs of tile rows halve the
+  // re-reads of the weight panels (measured 1141 -> 1085 us; 4 rows 1108, 8 rows 1167, 32 rows 1507)
+  if (p.group == 1 && N >= 8192 && M >= 2048) p.group = 2;
   { const char* e = getenv("SKHIP_GEMM_GROUP"); if (e) p.group = atoi(e); }
   const int esz = in_dtype == SK_BF16 ? 2 : 4;
   const int vecn = 16 / esz;
