@@ -649,3 +649,63 @@ def test_cast2d_multi_and_derived_weights(L):
     Ws[2].data.view(-1)[:5] = 7.0   # .data write: invisible to the version counter, like the Adam kernel
     ops.refresh_derived()
     check()
+
+
+@pytest.mark.parametrize("dtype,V", [(torch.float32, 23), (torch.bfloat16, 4096), (torch.bfloat16, 35000)])
+def test_xent_device_gradient_scale(L, dtype, V):
+    """A one-element device tensor multiplies the gradient (not the loss) in both loss kernels — the same bits
+    as the host-side scale of the same value."""
+    g = torch.Generator().manual_seed(V + 1)
+    T = 33
+    logits = rnd((T, V), dtype, g, 3.0).to(DEV)
+    gold = torch.randint(1, V, (T,), generator=g)
+    gold[::5] = 0
+    gold = gold.to(DEV)
+    scale = torch.tensor([0.6875], dtype=torch.float32, device=DEV)
+    outs = []
+    for kw in ({"grad_scale": 0.6875}, {"grad_scale_dev": scale}):
+        dl = torch.empty_like(logits)
+        stats = torch.zeros(3, dtype=torch.float64, device=DEV)
+        L.xent_fwd_bwd(logits, gold, dl, stats, 1.0, 0.1, 0, **kw)
+        outs.append((dl, stats))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    dl1 = torch.empty_like(logits)
+    L.xent_fwd_bwd(logits, gold, dl1, torch.zeros(3, dtype=torch.float64, device=DEV), 1.0, 0.1, 0)
+    assert rel_err(outs[1][0], dl1.float() * 0.6875) <= (1e-6 if dtype == torch.float32 else 8e-3)
+
+
+def test_empty_inputs_and_argument_errors(L):
+    """Zero-sized work is accepted and touches nothing; malformed arguments come back as SK_ERR_ARG with a
+    message (raised as RuntimeError by the binding) instead of launching."""
+    lib = L.load()
+    z = torch.zeros(8, 8, dtype=torch.bfloat16, device=DEV)
+    out = torch.full((8, 8), 7.0, dtype=torch.bfloat16, device=DEV)
+    L.gemm(L.GEMM_NT, z, z, 0, 8, 8, 8, 8, out=out, ldc=8)
+    L.gemm(L.GEMM_NT, z, z, 8, 0, 8, 8, 8, out=out, ldc=8)
+    assert (out == 7).all()
+    stats = torch.zeros(3, dtype=torch.float64, device=DEV)
+    L.xent_fwd_bwd(torch.empty(0, 16, dtype=torch.float32, device=DEV), torch.empty(0, dtype=torch.int64, device=DEV),
+                   None, stats, 1.0, 0.1, 0)
+    assert stats.abs().sum().item() == 0
+    assert L.softmax_rows(torch.empty(0, 16, dtype=torch.float32, device=DEV)).shape == (0, 16)
+    L.gemm_grouped_tn([])
+    emb = L.embed_fwd(torch.empty(0, dtype=torch.int64, device=DEV), torch.empty(0, dtype=torch.int64, device=DEV),
+                      torch.zeros(5, 8, device=DEV), torch.zeros(5, 8, device=DEV), torch.float32)
+    assert emb.shape == (0, 8)
+    # all-PAD rows: every loss row ignored, zero gradient
+    logits = torch.randn(4, 16, device=DEV)
+    dl = torch.full_like(logits, 3.0)
+    L.xent_fwd_bwd(logits, torch.zeros(4, dtype=torch.int64, device=DEV), dl, stats, 1.0, 0.1, 0)
+    assert stats.abs().sum().item() == 0 and dl.abs().sum().item() == 0
+    # errors
+    with pytest.raises(RuntimeError, match="leading dimension"):
+        L.gemm(L.GEMM_NT, z, z, 8, 8, 8, 4, 8, out=out, ldc=8)
+    with pytest.raises(RuntimeError, match="bad V"):
+        L.xent_fwd_bwd(torch.zeros(2, 1, device=DEV), torch.zeros(2, dtype=torch.int64, device=DEV), None, stats, 1.0, 0.0, 0)
+    with pytest.raises(RuntimeError, match="bad shape"):
+        lib_rc = lib.skhip_softmax_rows(z.data_ptr(), z.data_ptr(), 4, 8, 4, 8, 1, None)
+        L._check(lib_rc, "skhip_softmax_rows")
+    with pytest.raises(RuntimeError, match="bad dtype"):
+        L._check(lib.skhip_softmax_rows(z.data_ptr(), z.data_ptr(), 4, 8, 8, 8, 9, None), "skhip_softmax_rows")
+    with pytest.raises(RuntimeError):  # CPU tensors never reach a kernel
+        L.softmax_rows(torch.zeros(2, 4))
