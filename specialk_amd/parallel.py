@@ -18,9 +18,12 @@ import torch.distributed as dist
 
 
 class GradBucketReducer:
-    def __init__(self, params, bucket_mb=32, process_group=None):
+    def __init__(self, params, bucket_mb=32, process_group=None, always_reduce=False):
+        """always_reduce: run the collectives even in a group of one rank (a rehearsal of the RCCL path on a
+        single card: the sum over one rank leaves the gradients as they are)."""
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.active = self.world > 1 or (always_reduce and dist.is_initialized())
         self.params = [p for p in params if p.requires_grad]
         seen, uniq = set(), []
         for p in self.params:
@@ -44,10 +47,10 @@ class GradBucketReducer:
         self._hooks = []
         # A transport that cannot read device memory (gloo) gets the buckets through a host copy at
         # finish(); in-backward overlap is only for RCCL, which reduces the device buffers in place.
-        self._staged = (self.world > 1 and self.buckets and self.buckets[0][0].is_cuda
+        self._staged = (self.active and self.buckets and self.buckets[0][0].is_cuda
                         and dist.get_backend(process_group) != "nccl")
         self._bucket_of = {p.data_ptr(): bi for bi, (_, plist) in enumerate(self.buckets) for p in plist}
-        if self.world > 1 and not self._staged:
+        if self.active and not self._staged:
             for bi, (_, plist) in enumerate(self.buckets):
                 for p in plist:
                     self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(bi)))
@@ -72,7 +75,7 @@ class GradBucketReducer:
     def mark_ready(self, params):
         """Cue for gradients that were written into the bucket views directly instead of being
         accumulated by autograd (ops.batched_weight_grads): counts them like the hooks do."""
-        if self.world > 1 and not self._staged:
+        if self.active and not self._staged:
             for p in params:
                 self._make_hook(self._bucket_of[p.data_ptr()])(p)
 
@@ -103,7 +106,7 @@ class GradBucketReducer:
                 dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
                 flat.copy_(host)
                 self._pending[bi] = 0
-        elif self.world > 1:
+        elif self.active:
             for bi, (flat, _) in enumerate(self.buckets):
                 if self._pending[bi] > 0:
                     self._handles.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))

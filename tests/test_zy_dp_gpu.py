@@ -25,7 +25,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, out, packed, bf16=False):
+def _worker(rank, world, port, out, packed, bf16=False, backend="gloo"):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import faulthandler
@@ -36,14 +36,16 @@ def _worker(rank, world, port, out, packed, bf16=False):
     from test_model_gpu import build_tiny, load_sd, t
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     import datetime
-    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=90))
     torch.cuda.set_device(0)
+    extra = {"device_id": torch.device("cuda", 0)} if backend == "nccl" else {}
+    dist.init_process_group(backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=90), **extra)
     g = load_golden("transformer_untied")
     m = load_sd(build_tiny(g, False), split_prefixed(g, "w:")).eval()
     if bf16:
         m = m.set_compute_dtype(torch.bfloat16)
     params = [p for p in m.parameters() if p.requires_grad]
-    red = GradBucketReducer(params, bucket_mb=0.02)
+    red = GradBucketReducer(params, bucket_mb=0.02, always_reduce=True)
+    assert red.active and red._staged == (backend != "nccl")
     assert len(red.buckets) > 2
     batch = [t(g[k]) for k in ("src_seq", "src_pos", "tgt_seq", "tgt_pos")]
     per = batch[0].shape[0] // world
@@ -63,6 +65,8 @@ def _worker(rank, world, port, out, packed, bf16=False):
             loss.backward()
         red.finish()
     tot = all_reduce_scalars(stats, "cuda")
+    if world == 1:  # all_reduce_scalars has nothing to do for one rank: reduce a device tensor over the backend anyway
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
     if rank == 0:
         res = {"grads": {k: p.grad.cpu() for k, p in m.named_parameters() if p.grad is not None}, "stats": tot.cpu()}
         if bf16:  # reference for the bf16 run: the same arithmetic on the whole batch in one process, through autograd
@@ -104,3 +108,24 @@ def test_two_rank_step_bf16_grouped_weight_grads(tmp_path, packed):
     for k, ref in got["ref"].items():
         a, b = got["grads"][k].double(), ref.double()
         assert float((a - b).norm()) <= 3e-2 * float(b.norm()) + 1e-6, k
+
+
+@pytest.mark.parametrize("bf16", [False, True])
+def test_one_rank_rccl_rehearsal(tmp_path, bf16):
+    """The RCCL form of the exchange on the one card there is: a group of one rank over the nccl backend with
+    the reducer forced to reduce — hooks and grouped launches start asynchronous all-reduces of the device
+    buckets on RCCL's stream during backward, finish() waits for them, scalars are reduced on the device.
+    A sum over one rank changes nothing, so the gradients must equal the whole-batch gradients."""
+    out = str(tmp_path / "dp.pt")
+    mp.start_processes(_worker, args=(1, _free_port(), out, True, bf16, "nccl"), nprocs=1, join=True, start_method="forkserver")
+    got = torch.load(out)
+    if bf16:
+        for k, ref in got["ref"].items():
+            a, b = got["grads"][k].double(), ref.double()
+            assert float((a - b).norm()) <= 3e-2 * float(b.norm()) + 1e-6, k
+    else:
+        g = load_golden("transformer_untied")
+        assert abs(float(got["stats"][0]) - float(g["loss_ls"])) <= 1e-5 * float(g["loss_ls"])
+        for k, ref in split_prefixed(g, "g_ls:").items():
+            a, b = got["grads"][k].double().numpy(), ref.astype(np.float64)
+            assert np.abs(a - b).max() <= 1e-5 * np.abs(b).max() + 2e-6, k
