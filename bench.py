@@ -238,6 +238,12 @@ def main():
     ap.add_argument("--padded", action="store_true", help="keep padding rows (the reference's tensor shapes)")
     args = ap.parse_args()
 
+    # stdout carries exactly one line, the result: libraries that write to file descriptor 1 themselves (RCCL
+    # prints a version banner at start-up) are pointed at stderr for the whole run
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("SK_BENCH_DEVICE", os.environ.get("LOCAL_RANK", "0")))  # override: rehearsals on one card
@@ -247,8 +253,12 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    if world > 1:
+    # SK_BENCH_FORCE_DIST=1: run the N > 1 flow (process group, bucketed all-reduce, barriers, reductions of the
+    # results) in a group of ONE rank — a rehearsal of the RCCL calls on a single card
+    dist_on = world > 1 or os.environ.get("SK_BENCH_FORCE_DIST") == "1"
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         backend = os.environ.get("SK_BENCH_BACKEND", "nccl")  # "gloo": rehearsal of the N > 1 flow on one card
         dist.init_process_group(backend, rank=rank, world_size=world, **({"device_id": device} if backend == "nccl" else {}))
 
@@ -260,7 +270,7 @@ def main():
     from specialk_amd import ops
     from specialk_amd.parallel import GradBucketReducer
     ops.manual_seed(1000 + rank)
-    reducer = GradBucketReducer(list(m.parameters())) if world > 1 else None
+    reducer = GradBucketReducer(list(m.parameters()), always_reduce=True) if dist_on else None
 
     g = torch.Generator().manual_seed(7 + 1000 * rank)
     batches = []
@@ -273,7 +283,7 @@ def main():
     for i in range(args.warmup):
         train_step(m, opt, batches[i % len(batches)], reducer)
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -282,12 +292,12 @@ def main():
         train_step(m, opt, batches[i % len(batches)], reducer)
         tokens += tok_per_batch[i % len(batches)]
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
 
-    if world > 1:
+    if dist_on:
         red_dev = device if dist.get_backend() == "nccl" else "cpu"
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -307,7 +317,7 @@ def main():
                        "target_tokens_per_step": int(tokens / args.steps), "padding_rows": "skipped (packed)" if PACKED else "computed", "label_smoothing": True, "dropout": 0.1,
                        "optimizer": "Adam(0.9,0.98,1e-9)+Noam(4000)", "parallelism": f"dp{world}"},
         }
-    if world > 1:
+    if dist_on:
         dist.barrier()
     if rank == 0 and world == 1:
         if not args.no_roofline and args.dtype == "bf16":
@@ -317,8 +327,9 @@ def main():
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg)
     if rank == 0:
-        print(json.dumps(out), flush=True)
-    if world > 1:
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
 
