@@ -8,7 +8,9 @@ specialk_amd.optim); this file is host-side orchestration.  Differences from the
   * `-dtype {fp32,bf16}` (extension; default fp32 = the reference's arithmetic);
   * statistics (loss sum, correct, words) accumulate on the device and are read ONCE per epoch
     instead of three `.item()` syncs per step (lib/TransformerModel.py:428-430);
-  * under torch.distributed (one process per GPU) every rank takes a contiguous shard of each
+  * under torch.distributed (one process per GPU) `translate` decodes a contiguous shard of the
+    sentences per rank (no communication; rank 0 joins the output files in rank order); in training
+    every rank takes a contiguous shard of each
     batch and gradients are SUM-all-reduced in buckets over RCCL while backward runs — the
     multi-process replacement of nn.DataParallel (train.py:385-388).  The loss is a token sum,
     so the update equals the single-GPU update on the whole batch.
@@ -220,7 +222,18 @@ class TransformerModel(NMTModel):
         translator.model = self.model
         translator.max_token_seq_len = max_token_seq_len
         hypotheses = []
-        with open(self.opt.output, "w") as f:
+        # Under torch.distributed every rank decodes a contiguous shard of the sentences on its own GPU — the
+        # sentences are independent, nothing is exchanged — and rank 0 joins the shards' lines in rank order.
+        world, rank = _world(), _rank()
+        out_path = self.opt.output
+        if world > 1:
+            ds = test_loader.dataset
+            per = (len(ds) + world - 1) // world
+            shard = torch.utils.data.Subset(ds, range(min(len(ds), rank * per), min(len(ds), (rank + 1) * per)))
+            test_loader = torch.utils.data.DataLoader(shard, num_workers=0, batch_size=self.opt.batch_size,
+                                                      collate_fn=test_loader.collate_fn)
+            out_path = "{}.rank{}".format(self.opt.output, rank)
+        with open(out_path, "w") as f:
             for batch in test_loader:
                 all_hyp, _ = translator.translate_batch(*batch)
                 lines = self.translate_decode_bpe(all_hyp, decoder) if is_bpe else \
@@ -228,6 +241,17 @@ class TransformerModel(NMTModel):
                 for line in lines:
                     f.write(line + "\n")
                 hypotheses += all_hyp
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()  # every shard's file is complete
+            if rank == 0:
+                with open(self.opt.output, "w") as f:
+                    for r in range(world):
+                        part = "{}.rank{}".format(self.opt.output, r)
+                        with open(part) as g:
+                            f.write(g.read())
+                        os.remove(part)
+            dist.barrier()
         if self.opt.verbose:
             print("[Info] Finished.")
         return hypotheses

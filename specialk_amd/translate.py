@@ -5,8 +5,11 @@
         -checkpoint_decoder dec.chkpt -vocab corpus.pt -src test.txt -output predictions.txt
 
 Extension: `-dtype` (fp32 | bf16).  fp32 reproduces the reference's token sequences bit for bit.
+Several GPUs: `python -m torch.distributed.run --nproc-per-node N -m specialk_amd.translate ...` — each rank
+decodes a contiguous shard of the sentences, rank 0 writes the joined -output.
 """
 import argparse
+import os
 
 import torch
 
@@ -41,7 +44,15 @@ def main(argv=None):
     opt = load_args(argv)
     if opt.model != "transformer":
         raise SystemExit("-model recurrent is not implemented in this package (Transformer path only)")
-    if opt.cuda_device:
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:  # started by torch.distributed.run: one rank per GPU, each decodes its shard of the sentences
+        import torch.distributed as dist
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(local)
+        opt.cuda_device = local
+        if not dist.is_initialized():
+            dist.init_process_group("gloo")  # barriers only: decoding exchanges no tensors
+    elif opt.cuda_device:
         torch.cuda.set_device(opt.cuda_device)
     model = TransformerModel(opt)
     print("Setup model wrapper.")

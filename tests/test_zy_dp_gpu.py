@@ -129,3 +129,43 @@ def test_one_rank_rccl_rehearsal(tmp_path, bf16):
         for k, ref in split_prefixed(g, "g_ls:").items():
             a, b = got["grads"][k].double().numpy(), ref.astype(np.float64)
             assert np.abs(a - b).max() <= 1e-5 * np.abs(b).max() + 2e-6, k
+
+
+def _translate_worker(rank, world, port, argv):
+    sys.path.insert(0, ROOT)
+    import faulthandler
+    faulthandler.dump_traceback_later(60, exit=True)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    from specialk_amd import translate as translate_cli
+    translate_cli.main(argv)
+    import torch.distributed as dist
+    dist.destroy_process_group()
+
+
+def test_translate_shards_sentences_over_ranks(tmp_path, monkeypatch):
+    """Three ranks (all on cuda:0) translate contiguous shards of seven sentences; the joined output equals the
+    one-process output line for line (no communication: beam search of a sentence does not depend on its batch)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_cli_gpu import make_corpus
+    from specialk_amd import translate as translate_cli
+    from specialk_amd.train import load_args, train_model
+    monkeypatch.chdir(tmp_path)
+    data_path = str(tmp_path / "toy.pt")
+    make_corpus(data_path, n_train=48, n_valid=8)
+    train_model(load_args().parse_args([
+        "-data", data_path, "-model", "transformer", "-epochs", "1", "-batch_size", "8", "-layers", "1",
+        "-d_model", "32", "-d_word_vec", "32", "-d_inner_hid", "64", "-d_k", "8", "-d_v", "8", "-n_head", "4",
+        "-n_warmup_steps", "10", "-save_model", "-directory_name", "run", "-seed", "5"]))
+    run = tmp_path / "models" / "run"
+    rng = np.random.default_rng(1)
+    sents = [" ".join(f"w{int(i)}" for i in rng.integers(4, 39, size=int(rng.integers(1, 9)))) for _ in range(7)]
+    (tmp_path / "in.txt").write_text("\n".join(sents) + "\n")
+    common = ["-model", "transformer", "-src", str(tmp_path / "in.txt"), "-vocab", data_path,
+              "-checkpoint_encoder", str(run / "encoder_epoch_1.chkpt"), "-checkpoint_decoder", str(run / "decoder_epoch_1.chkpt"),
+              "-batch_size", "2", "-beam_size", "3", "-n_best", "1"]
+    translate_cli.main(common + ["-output", str(tmp_path / "one.txt")])
+    mp.start_processes(_translate_worker, args=(3, _free_port(), common + ["-output", str(tmp_path / "many.txt")]),
+                       nprocs=3, join=True, start_method="forkserver")
+    one, many = (tmp_path / "one.txt").read_text(), (tmp_path / "many.txt").read_text()
+    assert len(one.split("\n")) == 8 and one == many
+    assert not list(tmp_path.glob("many.txt.rank*"))
