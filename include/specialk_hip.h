@@ -185,6 +185,13 @@ int skhip_embed_bwd(const int64_t* seq, const void* dout, float* dword_emb, int6
 int skhip_pack_plan(const int64_t* seq, int B, int L, int trim, int64_t pad_id, int32_t* lens,
                     int32_t* off, int64_t* idx, int64_t* facts, void* stream);
 
+/* Batch collation on the device (collate_fn, core/dataset.py:21-46): the B sentences of a batch arrive as one
+ * flat id array (sentence b = flat[off[b] .. off[b+1]-1], off[B+1] int64) and are written right-padded with
+ * pad_id into seq [B][L] (L >= the longest sentence; longer sentences are cut at L), with pos [B][L] =
+ * index + 1 on real ids and 0 on padding.                                                     */
+int skhip_collate(const int64_t* flat, const int64_t* off, int B, int L, int64_t pad_id, int64_t* seq,
+                  int64_t* pos, void* stream);
+
 /* ---- label-smoothed softmax cross-entropy, forward + backward + accuracy -------------
  * Replaces calculate_loss / performance (lib/TransformerModel.py:340-375).
  * logits [T][V] (ld = ldl) are multiplied by `logit_scale` first (x_logit_scale,

@@ -23,7 +23,7 @@ EXPORTS = [
     "skhip_attn_bwd", "skhip_attn_varlen_fwd", "skhip_attn_varlen_bwd", "skhip_add_ln_fwd", "skhip_add_ln_bwd_ws_floats", "skhip_add_ln_bwd", "skhip_embed_fwd",
     "skhip_embed_bwd", "skhip_pack_plan", "skhip_xent_fwd_bwd", "skhip_adam_multi", "skhip_cast_multi", "skhip_cast2d_multi", "skhip_convert",
     "skhip_decode_attn", "skhip_beam_topk_ws_bytes", "skhip_beam_topk", "skhip_gather_rows",
-    "skhip_softmax_rows", "skhip_conv_windows", "skhip_cnn_head",
+    "skhip_softmax_rows", "skhip_conv_windows", "skhip_cnn_head", "skhip_collate",
 ]
 
 _lib = None
@@ -48,6 +48,7 @@ def load():
     lib.skhip_beam_topk_ws_bytes.restype = c_i64
     lib.skhip_beam_topk_ws_bytes.argtypes = [c_int, c_int, c_i64]
     lib.skhip_pack_plan.argtypes = [c_p, c_int, c_int, c_int, c_i64, c_p, c_p, c_p, c_p, c_p]
+    lib.skhip_collate.argtypes = [c_p, c_p, c_int, c_int, c_i64, c_p, c_p, c_p]
     lib.skhip_gemm_grouped_tn.argtypes = [ctypes.POINTER(c_i64), c_int, c_p, c_i64, c_p]
     lib.skhip_gemm.argtypes = [c_int, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_f32,
                                c_int, c_int, c_int, c_p, c_i64, c_p]
@@ -260,6 +261,15 @@ def pack_plan(seq, trim, pad_id):
     _check(lib.skhip_pack_plan(_ptr(seq), B, L, int(trim), int(pad_id), _ptr(lens), _ptr(off), _ptr(idx), _ptr(facts),
                                _stream()), "skhip_pack_plan")
     return lens, off, idx, facts
+
+
+def collate(flat, off, B, L, pad_id):
+    """flat int64 ids and off int64 (B+1,) on the GPU -> (seq, pos) int64 (B, L), right-padded."""
+    lib = load()
+    seq = torch.empty((B, L), dtype=torch.int64, device=flat.device)
+    pos = torch.empty((B, L), dtype=torch.int64, device=flat.device)
+    _check(lib.skhip_collate(_ptr(flat), _ptr(off), B, L, int(pad_id), _ptr(seq), _ptr(pos), _stream()), "skhip_collate")
+    return seq, pos
 
 
 def embed_bwd(seq, dout, dword_emb, pad_id):

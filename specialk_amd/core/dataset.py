@@ -24,6 +24,25 @@ def paired_collate_fn(insts):
     return (*collate_fn(src_insts), *collate_fn(tgt_insts))
 
 
+def device_collate_fn(insts, device=None):
+    """collate_fn with the padding done on the GPU: the sentences travel as one flat id array plus offsets
+    (two host -> device copies) and a kernel writes the padded (seq, pos) pair.  Same result as collate_fn."""
+    from .. import _lib as L
+    device = torch.device("cuda", torch.cuda.current_device()) if device is None else device
+    lens = np.fromiter((len(x) for x in insts), dtype=np.int64, count=len(insts))
+    off = np.zeros(len(insts) + 1, dtype=np.int64)
+    np.cumsum(lens, out=off[1:])
+    flat = np.fromiter((t for x in insts for t in x), dtype=np.int64, count=int(off[-1]))
+    host = torch.from_numpy(np.concatenate([off, flat])).pin_memory()
+    dev = host.to(device, non_blocking=True)
+    return L.collate(dev[len(off):], dev[:len(off)], len(insts), int(lens.max()), Constants.PAD)
+
+
+def paired_device_collate_fn(insts, device=None):
+    src_insts, tgt_insts = list(zip(*insts))
+    return (*device_collate_fn(src_insts, device), *device_collate_fn(tgt_insts, device))
+
+
 class TokenBudgetBatchSampler(torch.utils.data.Sampler):
     """Length-bucketed batches under a token budget, for `DataLoader(batch_sampler=...)`.
 

@@ -103,6 +103,21 @@ __global__ __launch_bounds__(256) void pack_index_kernel(const int32_t* __restri
   }
 }
 
+// seq[b][i] = i-th id of sentence b (its ids are flat[off[b] .. off[b+1]-1]) or pad_id past its end;
+// pos[b][i] = i + 1 where seq holds a real id, else 0
+__global__ __launch_bounds__(256) void collate_kernel(const int64_t* __restrict__ flat, const int64_t* __restrict__ off,
+                                                      int B, int L, int64_t pad_id, int64_t* __restrict__ seq,
+                                                      int64_t* __restrict__ pos) {
+  const int64_t total = (int64_t)B * L;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int b = (int)(e / L), i = (int)(e - (int64_t)b * L);
+    const int64_t lo = off[b], len = off[b + 1] - lo;
+    const int64_t id = i < len ? flat[lo + i] : pad_id;
+    seq[e] = id;
+    pos[e] = id != pad_id ? i + 1 : 0;
+  }
+}
+
 }  // namespace
 
 extern "C" int skhip_embed_fwd(const int64_t* seq, const int64_t* pos, const float* word_emb, const float* pos_table,
@@ -157,5 +172,18 @@ extern "C" int skhip_pack_plan(const int64_t* seq, int B, int L, int trim, int64
     hipLaunchKernelGGL(pack_index_kernel, dim3(blocks), dim3(256), 0, stream, off, B, L, idx);
     SK_CHECK_LAUNCH("skhip_pack_plan(index)");
   }
+  return SK_OK;
+}
+
+extern "C" int skhip_collate(const int64_t* flat, const int64_t* off, int B, int L, int64_t pad_id, int64_t* seq,
+                             int64_t* pos, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SK_CHECK_ARG(B >= 0 && L >= 0 && (int64_t)B * L < (1ll << 31), "skhip_collate: bad shape %d x %d", B, L);
+  if (B == 0 || L == 0) return SK_OK;
+  SK_CHECK_ARG(flat && off && seq && pos, "skhip_collate: null pointer");
+  const int64_t total = (int64_t)B * L;
+  const unsigned blocks = (unsigned)std::min<int64_t>((total + 255) / 256, 4096);
+  hipLaunchKernelGGL(collate_kernel, dim3(blocks), dim3(256), 0, stream, flat, off, B, L, pad_id, seq, pos);
+  SK_CHECK_LAUNCH("skhip_collate");
   return SK_OK;
 }

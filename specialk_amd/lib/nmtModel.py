@@ -20,7 +20,8 @@ import torch.utils.data
 
 from ..core import constants
 from ..core.bpe import Encoder as BPE
-from ..core.dataset import TokenBudgetBatchSampler, TranslationDataset, collate_fn, paired_collate_fn
+from ..core.dataset import (TokenBudgetBatchSampler, TranslationDataset, collate_fn, paired_collate_fn,
+                            paired_device_collate_fn)
 
 
 def _rank():
@@ -172,6 +173,8 @@ class NMTModel:
     def init_dataloaders(data, opt):
         src_word2idx, _ = NMTModel._flatten_vocab(data["dict"]["src"])
         tgt_word2idx, _ = NMTModel._flatten_vocab(data["dict"]["tgt"])
+        # -device_collate: pad the batches on the GPU (loaders run in this process: num_workers = 0)
+        pair_fn = paired_device_collate_fn if getattr(opt, "device_collate", False) else paired_collate_fn
         def loader(split, shuffle):
             ds = TranslationDataset(src_word2idx=src_word2idx, tgt_word2idx=tgt_word2idx,
                                     src_insts=data[split]["src"], tgt_insts=data[split]["tgt"])
@@ -179,9 +182,9 @@ class NMTModel:
             if budget > 0:  # length-bucketed batches of at most `budget` tokens and -batch_size sentences
                 sampler = TokenBudgetBatchSampler.for_dataset(ds, budget, max_sentences=opt.batch_size, shuffle=shuffle,
                                                               seed=int(getattr(opt, "seed", 0) or 0))
-                return torch.utils.data.DataLoader(ds, num_workers=0, batch_sampler=sampler, collate_fn=paired_collate_fn)
+                return torch.utils.data.DataLoader(ds, num_workers=0, batch_sampler=sampler, collate_fn=pair_fn)
             return torch.utils.data.DataLoader(ds, num_workers=0, batch_size=opt.batch_size,
-                                               collate_fn=paired_collate_fn, shuffle=shuffle)
+                                               collate_fn=pair_fn, shuffle=shuffle)
         train_loader, valid_loader = loader("train", True), loader("valid", False)
         if opt.embs_share_weight:
             assert train_loader.dataset.src_word2idx == train_loader.dataset.tgt_word2idx, \

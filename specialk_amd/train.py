@@ -76,6 +76,8 @@ def load_args():
     p.add_argument("-batch_tokens", type=int, default=0,
                    help="> 0: length-bucketed batches of at most this many tokens (and -batch_size sentences) "
                         "instead of the reference's fixed sentence count")
+    p.add_argument("-device_collate", action="store_true",
+                   help="pad the batches on the GPU (flat ids + offsets are copied, a kernel writes seq / pos)")
     return p
 
 

@@ -203,7 +203,7 @@ def test_bpe_dataset_trains_and_translates_text(tmp_path, monkeypatch):
     model = train_model(load_args().parse_args([
         "-data", data_path, "-model", "transformer", "-epochs", "1", "-batch_size", "16", "-layers", "1",
         "-d_model", "32", "-d_word_vec", "32", "-d_inner_hid", "64", "-d_k", "8", "-d_v", "8", "-n_head", "4",
-        "-n_warmup_steps", "10", "-save_model", "-directory_name", "bpe", "-seed", "3"]))
+        "-n_warmup_steps", "10", "-save_model", "-directory_name", "bpe", "-seed", "3", "-device_collate"]))
     assert model.tgt_bpe is not None and model.src_bpe is not None
     run = tmp_path / "models" / "bpe"
     src_txt = tmp_path / "in.txt"

@@ -709,3 +709,17 @@ def test_empty_inputs_and_argument_errors(L):
         L._check(lib.skhip_softmax_rows(z.data_ptr(), z.data_ptr(), 4, 8, 8, 8, 9, None), "skhip_softmax_rows")
     with pytest.raises(RuntimeError):  # CPU tensors never reach a kernel
         L.softmax_rows(torch.zeros(2, 4))
+
+
+def test_device_collate_matches_host_collate(L):
+    from specialk_amd.core.dataset import collate_fn, device_collate_fn, paired_collate_fn, paired_device_collate_fn
+    rng = np.random.default_rng(2)
+    insts = [[2] + rng.integers(0, 30, size=int(n)).tolist() + [3] for n in rng.integers(0, 17, size=23)]  # ids may be PAD
+    seq, pos = collate_fn(insts)
+    dseq, dpos = device_collate_fn(insts)
+    assert dseq.is_cuda and torch.equal(dseq.cpu(), seq) and torch.equal(dpos.cpu(), pos)
+    pairs = list(zip(insts, insts[::-1]))
+    for a, b in zip(paired_collate_fn(pairs), paired_device_collate_fn(pairs)):
+        assert torch.equal(a, b.cpu())
+    one = device_collate_fn([[2, 3]])
+    assert one[0].tolist() == [[2, 3]] and one[1].tolist() == [[1, 2]]
