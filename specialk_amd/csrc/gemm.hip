@@ -1166,6 +1166,9 @@ static int gemm_one(int layout, const void* A, const void* B, void* C, const voi
   // (weight gradients) and long-K NN (generator input gradient).  SKHIP_GEMM_STAGED=0/1 forces one.
   const char* env_staged = getenv("SKHIP_GEMM_STAGED");
   bool use_staged = layout == SK_GEMM_TN || (layout == SK_GEMM_NN && K >= 8192);
+  // a few hundred rows against a long contraction with split-K (decode step, 640 x 512 x 2048): the
+  // register-staged kernel's BK = 64 halves the serial K-steps of each split (18 vs 24 us per call)
+  if (layout == SK_GEMM_NT && M <= 1024 && K >= 2048 && workspace) use_staged = true;
   if (env_staged && (env_staged[0] == '0' || env_staged[0] == '1')) use_staged = env_staged[0] == '1';
   // 256x256-tile kernel: K-contiguous operands (NT).  One block per CU, so what decides is how
   // well the 256-tiles fill whole rounds of the chip (measured, 256 CUs, M = 25k..33k rows):
