@@ -47,7 +47,7 @@ class Encoder:
                  required_tokens=None, strict=False, EOW=DEFAULT_EOW, SOW=DEFAULT_SOW, UNK=DEFAULT_UNK,
                  PAD=DEFAULT_PAD):
         if vocab_size < 1:
-            raise ValueError("vocab size must be greater than 0.")
+            raise ValueError("vocab_size must be at least 1")
         self.EOW, self.SOW, self.UNK, self.PAD = EOW, SOW, UNK, PAD
         self.eow_len, self.sow_len = len(EOW), len(SOW)
         self.required_tokens = required_tokens if required_tokens else _required_tokens()
@@ -163,45 +163,45 @@ class Encoder:
                 ids = ids[:fixed_length] + [self.word_vocab[self.PAD]] * max(0, fixed_length - len(ids))
             yield ids[::step]
 
+    def _decode_row(self, row):
+        """Ids of one sentence -> its words: pieces between the word markers are glued into one word."""
+        pieces, whole = self.inverse_bpe_vocab, self.inverse_word_vocab
+        out, buf, inside = [], [], False
+        for i in row:
+            text = pieces.get(i)
+            if text == self.SOW or text == self.EOW:
+                opening = text == self.SOW
+                if self.strict and opening == inside:
+                    raise ValueError("word start marker inside an unfinished word" if opening else
+                                     "word end marker without a word start")
+                if not opening:
+                    out.append("".join(buf))
+                    buf = []
+                inside = opening
+                continue
+            if text is None:
+                text = whole.get(i)
+                if text is None:
+                    raise ValueError("id {} is in neither vocabulary".format(i))
+            elif not inside:
+                if i in whole:  # an id both vocabularies hold reads as a word outside a word's pieces
+                    text = whole[i]
+                elif self.strict:
+                    raise ValueError("piece id {} outside a word".format(i))
+            (buf if inside else out).append(text)
+        return [w for w in out if w]
+
     def inverse_transform(self, rows):
         for row in rows:
-            words, current, rebuilding = [], "", False
-            for idx in row:
-                piece = self.inverse_bpe_vocab.get(idx)
-                if piece == self.SOW:
-                    if rebuilding and self.strict:
-                        raise ValueError("Encountered second SOW token before EOW.")
-                    rebuilding = True
-                elif piece == self.EOW:
-                    if not rebuilding and self.strict:
-                        raise ValueError("Encountered EOW without matching SOW.")
-                    rebuilding = False
-                    words.append(current)
-                    current = ""
-                elif rebuilding and piece is not None:
-                    current += piece
-                elif rebuilding and idx in self.inverse_word_vocab:
-                    current += self.inverse_word_vocab[idx]
-                elif idx in self.inverse_word_vocab:
-                    words.append(self.inverse_word_vocab[idx])
-                elif piece is not None:
-                    if self.strict:
-                        raise ValueError("Found BPE index {} when not rebuilding word!".format(idx))
-                    words.append(piece)
-                else:
-                    raise ValueError("Got index {} that was not in word or BPE vocabs!".format(idx))
-            yield " ".join(w for w in words if w != "")
+            yield " ".join(self._decode_row(row))
 
     # ------------------------------------------------------------------ persistence
     def vocabs_to_dict(self, dont_warn=False):
         if self.custom_tokenizer and not dont_warn:
-            print("WARNING! You've specified a non-default tokenizer.  You'll need to reassign it when you load the "
-                  "model!")
-        return {"byte_pairs": self.bpe_vocab, "words": self.word_vocab,
-                "kwargs": {"vocab_size": self.vocab_size, "pct_bpe": self.pct_bpe, "silent": self.silent,
-                           "ngram_min": self.ngram_min, "ngram_max": self.ngram_max,
-                           "required_tokens": self.required_tokens, "strict": self.strict, "EOW": self.EOW,
-                           "SOW": self.SOW, "UNK": self.UNK, "PAD": self.PAD}}
+            print("[Warning] the word tokenizer is not the default one and is not saved: pass it again after loading")
+        ctor = {name: getattr(self, name) for name in ("vocab_size", "pct_bpe", "silent", "ngram_min", "ngram_max",
+                                                        "required_tokens", "strict", "EOW", "SOW", "UNK", "PAD")}
+        return {"byte_pairs": self.bpe_vocab, "words": self.word_vocab, "kwargs": ctor}
 
     def save(self, outpath, dont_warn=False):
         with open(outpath, "w") as f:
@@ -210,10 +210,9 @@ class Encoder:
     @classmethod
     def from_dict(cls, vocabs):
         enc = cls(**vocabs["kwargs"])
-        enc.word_vocab = vocabs["words"]
-        enc.bpe_vocab = vocabs["byte_pairs"]
-        enc.inverse_bpe_vocab = {v: k for k, v in enc.bpe_vocab.items()}
-        enc.inverse_word_vocab = {v: k for k, v in enc.word_vocab.items()}
+        enc.word_vocab, enc.bpe_vocab = vocabs["words"], vocabs["byte_pairs"]
+        enc.inverse_word_vocab = dict(map(reversed, enc.word_vocab.items()))
+        enc.inverse_bpe_vocab = dict(map(reversed, enc.bpe_vocab.items()))
         return enc
 
     @classmethod

@@ -1,10 +1,14 @@
-"""Per-sentence beam state with the reference's interface (lib/transformer/Beam.py:14-110).
+"""One sentence's beam with the interface of the reference's Beam (lib/transformer/Beam.py:14-110): `size`,
+`scores`, `all_scores`, `prev_ks`, `next_ys`, `done`, `advance`, `sort_scores`, `get_current_state`,
+`get_current_origin`, `get_the_best_score_and_idx`, `get_tentative_hypothesis`, `get_hypothesis`.
 
-The translator in this package keeps all beams of a batch in device tensors
-(specialk_amd.decode.BeamDecoder); this class exists for callers that drive a single beam by
-hand.  advance() runs the same fused top-k kernel.  The back-pointer `prev_k` is the integer
-(floor) quotient of the flat id by the vocabulary size — what the reference's `/` meant on the
-torch version it was written for (Beam.py:70).
+The translator of this package holds the beams of a whole batch in device tensors
+(specialk_amd.decode.BeamDecoder); this class serves callers that step a single beam by hand, and
+`advance` runs the same fused top-k kernel.  Semantics kept from the reference: the first step expands only
+row 0 (the other rows start as PAD), later steps rank `word_prob + scores[:, None]` over beam x vocabulary;
+the back-pointer is the FLOOR quotient of the flat index by the vocabulary size (the reference's `/` at
+Beam.py:70 was integer division on the torch it was written for); a beam is done once its best entry is EOS;
+hypotheses are read by walking the back-pointers.
 """
 import torch
 
@@ -13,70 +17,62 @@ from ...core import constants as Constants
 
 
 class Beam:
-    """Beam search"""
-
     def __init__(self, size, device=False):
+        where = device or "cuda"
+        start = torch.full((size,), Constants.PAD, dtype=torch.long, device=where)
+        start[0] = Constants.SOS
         self.size = size
-        self._done = False
-        dev = device if device else "cuda"
-        self.scores = torch.zeros((size,), dtype=torch.float, device=dev)
+        self.scores = torch.zeros(size, dtype=torch.float, device=where)
+        self.next_ys = [start]   # tokens chosen at every step
+        self.prev_ks = []        # beam row each of them extends
         self.all_scores = []
-        self.prev_ks = []
-        self.next_ys = [torch.full((size,), Constants.PAD, dtype=torch.long, device=dev)]
-        self.next_ys[0][0] = Constants.SOS
+        self._done = False
 
-    def get_current_state(self):
-        "Get the outputs for the current timestep."
-        return self.get_tentative_hypothesis()
-
-    def get_current_origin(self):
-        "Get the backpointers for the current timestep."
-        return self.prev_ks[-1]
-
-    @property
-    def done(self):
-        return self._done
+    done = property(lambda self: self._done)
 
     def advance(self, word_prob):
-        "Update beam status with log-probabilities (size, n_words) and check if finished or not."
-        word_prob = word_prob.to(torch.float32).contiguous()
-        first = len(self.prev_ks) == 0
-        scores, prev, tok = L.beam_topk(word_prob, self.scores.view(1, -1).contiguous(), 1, self.size, first,
-                                        normalize=False)
+        """word_prob (size, n_words) log-probabilities of the next token -> True once the best entry is EOS."""
+        logp = word_prob.to(torch.float32).contiguous()
+        new_scores, origin, token = L.beam_topk(logp, self.scores.view(1, -1).contiguous(), 1, self.size,
+                                                not self.prev_ks, normalize=False)
         self.all_scores.append(self.scores)
-        self.scores = scores.view(-1)
-        self.prev_ks.append(prev.view(-1).long())
-        self.next_ys.append(tok.view(-1).long())
-        # End condition is when top-of-beam is EOS.
-        if self.next_ys[-1][0].item() == Constants.EOS:
-            self._done = True
+        self.scores = new_scores.view(-1)
+        self.prev_ks.append(origin.view(-1).long())
+        self.next_ys.append(token.view(-1).long())
+        if int(self.next_ys[-1][0]) == Constants.EOS:
             self.all_scores.append(self.scores)
+            self._done = True
         return self._done
 
     def sort_scores(self):
-        "Sort the scores."
         return torch.sort(self.scores, 0, True)
 
     def get_the_best_score_and_idx(self):
-        "Get the score of the best in the beam."
-        scores, ids = self.sort_scores()
-        return scores[1], ids[1]
+        # the reference returns entry 1 of the sorted beam (Beam.py:85-88); kept as it is
+        ranked, order = self.sort_scores()
+        return ranked[1], order[1]
+
+    def get_current_origin(self):
+        return self.prev_ks[-1]
+
+    def get_current_state(self):
+        return self.get_tentative_hypothesis()
 
     def get_tentative_hypothesis(self):
-        "Get the decoded sequence for the current timestep."
-        if len(self.next_ys) == 1:
+        """(size, t) token ids of the live hypotheses, best first, each starting with SOS."""
+        if not self.prev_ks:
             return self.next_ys[0].unsqueeze(1)
-        _, keys = self.sort_scores()
-        hyps = [[Constants.SOS] + self.get_hypothesis(k) for k in keys]
-        return torch.LongTensor(hyps)
+        order = self.sort_scores()[1]
+        return torch.LongTensor([[Constants.SOS] + self.get_hypothesis(k) for k in order])
 
     def get_hypothesis(self, k):
-        """Walk back to construct the full hypothesis."""
-        k = int(k)
-        ys = [y.tolist() for y in self.next_ys]
-        ks = [p.tolist() for p in self.prev_ks]
-        hyp = []
-        for j in range(len(ks) - 1, -1, -1):
-            hyp.append(ys[j + 1][k])
-            k = ks[j][k]
-        return hyp[::-1]
+        """Tokens of the hypothesis that ends in beam row k (without SOS)."""
+        row = int(k)
+        tokens = [y.tolist() for y in self.next_ys[1:]]
+        origins = [p.tolist() for p in self.prev_ks]
+        out = []
+        for step in reversed(range(len(origins))):
+            out.append(tokens[step][row])
+            row = origins[step][row]
+        out.reverse()
+        return out

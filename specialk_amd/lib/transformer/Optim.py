@@ -1,34 +1,44 @@
-"""Learning-rate schedule wrapper with the reference's interface
-(lib/transformer/Optim.py:6-39):  lr = d_model^-0.5 * min(n^-0.5, n * warmup^-1.5),
-with the step counter incremented BEFORE the rate is computed."""
-import numpy as np
+"""Noam learning-rate schedule around an optimiser, with the interface of the reference's
+ScheduledOptim (lib/transformer/Optim.py:6-39): `step_and_update_lr()`, `zero_grad()`, and the attributes
+`_optimizer`, `n_warmup_steps`, `n_current_steps`, `init_lr`.
+
+    lr(n) = d_model^-0.5 * min(n^-0.5, n * n_warmup_steps^-1.5)
+
+where n counts calls of step_and_update_lr() and is incremented BEFORE the rate is evaluated, so the first
+update uses lr(1).  The rate replaces whatever `lr` the optimiser was built with.
+"""
+import math
+
+
+def noam_lr(step, d_model, n_warmup_steps):
+    """Rate of update number `step` (1-based)."""
+    warm = step * n_warmup_steps ** -1.5
+    decay = 1.0 / math.sqrt(step)
+    return min(decay, warm) / math.sqrt(d_model)
 
 
 class ScheduledOptim:
-    """A simple wrapper class for learning rate scheduling."""
-
     def __init__(self, optimizer, d_model, n_warmup_steps):
         self._optimizer = optimizer
+        self._d_model = d_model
         self.n_warmup_steps = n_warmup_steps
         self.n_current_steps = 0
-        self.init_lr = np.power(d_model, -0.5)
+        self.init_lr = d_model ** -0.5
+
+    # reference-named helpers, kept for callers that poke at them
+    def _get_lr_scale(self):
+        return noam_lr(self.n_current_steps, 1.0, self.n_warmup_steps)
+
+    def _update_learning_rate(self):
+        self.n_current_steps += 1
+        rate = noam_lr(self.n_current_steps, self._d_model, self.n_warmup_steps)
+        for group in self._optimizer.param_groups:
+            group["lr"] = rate
+        return rate
 
     def step_and_update_lr(self):
-        "Step with the inner optimizer"
         self._update_learning_rate()
         self._optimizer.step()
 
     def zero_grad(self):
-        "Zero out the gradients by the inner optimizer"
         self._optimizer.zero_grad()
-
-    def _get_lr_scale(self):
-        n = self.n_current_steps
-        return np.min([np.power(n, -0.5), np.power(self.n_warmup_steps, -1.5) * n])
-
-    def _update_learning_rate(self):
-        """Learning rate scheduling per step"""
-        self.n_current_steps += 1
-        lr = self.init_lr * self._get_lr_scale()
-        for param_group in self._optimizer.param_groups:
-            param_group["lr"] = lr
