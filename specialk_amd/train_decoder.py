@@ -160,7 +160,12 @@ def _style_batch(self, class_input, class_model, batch, smooth, want_logits=Fals
     if getattr(self, "packed", True) and not want_logits:
         try:
             tgt_in, tgt_pos_in = tgt_seq[:, :-1].contiguous(), tgt_pos[:, :-1].contiguous()
-            src_plan, tgt_plan = plan_packing([src_seq, tgt_in], [0, 0])
+            check = None
+            if m.encoder.check_ids:  # ids / positions outside their tables must raise, not reach a kernel
+                enc, dec = m.encoder, m.decoder
+                check = [(src_seq, enc.src_word_emb.num_embeddings), (src_pos, enc.position_enc.num_embeddings),
+                         (tgt_in, dec.tgt_word_emb.num_embeddings), (tgt_pos_in, dec.position_enc.num_embeddings)]
+            src_plan, tgt_plan = plan_packing([src_seq, tgt_in], [0, 0], check)
             with torch.no_grad():
                 enc_packed = m.encoder.forward_packed(src_seq, src_pos, src_plan)
             dec_packed = m.decoder.forward_packed(tgt_in, tgt_pos_in, tgt_plan, enc_packed, src_plan)

@@ -193,6 +193,21 @@ def test_style_training_steps_fp32(name, packed):
     assert len(out[0]) == 1 and all(torch.equal(v, before[k]) for k, v in m.state_dict().items())
 
 
+def test_style_batch_rejects_ids_outside_the_tables():
+    from specialk_amd import train_decoder as TD
+    g = load_golden("style_pad")
+    m = load_sd(build_tiny(g, True, dropout=0.0), split_prefixed(g, "w0:")).eval()
+    cnn, class_input = make_convnet(g), make_class_input(g)
+    trainer = SimpleNamespace(model=m, device=torch.device(DEV), packed=True, opt=Namespace(label_smoothing=False))
+    batch = [torch.from_numpy(g[f"{n}_0"]).clone() for n in ("src_seq", "src_pos", "tgt_seq", "tgt_pos")]
+    batch[2][0, 1] = int(g["vocab"][1]) + 5
+    with pytest.raises(IndexError):
+        TD._style_batch(trainer, class_input, cnn, batch, False)
+    trainer.packed = False
+    with pytest.raises(IndexError):
+        TD._style_batch(trainer, class_input, cnn, batch, False)
+
+
 def test_style_step_bf16_close_to_fp32():
     from specialk_amd import train_decoder as TD
     g = load_golden("style_pad")
