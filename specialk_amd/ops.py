@@ -10,6 +10,7 @@ import itertools
 import weakref
 
 import contextlib
+import os
 
 import torch
 
@@ -170,6 +171,33 @@ def _bias_grad(dy, T, N):
     return L.colsum(dy, T, N, N)
 
 
+_side_streams = {}
+
+
+def _colsum_overlapped(dy, T, N, ld, biases):
+    """Column sums of dy (T, N; row stride ld) = the gradients of `biases` (the parameters the result is
+    split over).  Inside batched_weight_grads() on a single GPU the HBM-bound reduction runs on a second
+    stream beside the latency-bound input-gradient GEMMs of the main stream; the context joins the streams
+    when it exits, before anything reads a gradient.  Not taken when a reducer consumes gradients during
+    backward (on_ready) or when a bias already holds a gradient (autograd would then add to it on the main
+    stream straight away)."""
+    b = _wgrad_batch
+    if b is None or b.on_ready is not None or not b.overlap or any(p.grad is not None for p in biases):
+        return L.colsum(dy, T, N, ld)
+    main = torch.cuda.current_stream(dy.device)
+    side = _side_streams.get(dy.device)
+    if side is None:
+        side = _side_streams[dy.device] = torch.cuda.Stream(dy.device)
+    out = torch.empty(N, dtype=torch.float32, device=dy.device)
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        L.colsum(dy, T, N, ld, out=out)
+    dy.record_stream(side)
+    out.record_stream(side)
+    b.side = side
+    return out
+
+
 def _residual_grad(dy):
     """The residual-branch gradient that AddLNFn.backward attached to dy (see there), or None."""
     pre = getattr(dy, "_sk_dres", None)
@@ -231,6 +259,8 @@ class _WeightGradBatch:
     def __init__(self, on_ready, flush_tiles):
         self.on_ready, self.flush_tiles = on_ready, flush_tiles
         self.items, self.tiles, self.seen = [], 0, set()
+        self.side = None  # second stream, once a bias-gradient reduction has been put on it
+        self.overlap = os.environ.get("SK_COLSUM_OVERLAP", "1") != "0"
 
 
 _wgrad_batch = None
@@ -258,6 +288,8 @@ def batched_weight_grads(on_ready=None, flush_tiles=256):
     try:
         yield
         _flush_weight_grads()
+        if _wgrad_batch.side is not None:  # bias-gradient reductions on the second stream: join
+            torch.cuda.current_stream().wait_stream(_wgrad_batch.side)
     finally:
         _wgrad_batch = None
 
@@ -370,13 +402,13 @@ class FFNFn(torch.autograd.Function):
         h = L.gemm(L.GEMM_NT, x, W1c, T, F, d, x.stride(0), d, bias=b1.detach(), aux=signs,
                    epilogue=L.EPI_RELU | (L.EPI_RELU_BITS_OUT if signs is not None else 0))
         y = L.gemm(L.GEMM_NT, h, W2c, T, d, F, F, F, bias=b2.detach())
-        ctx.save_for_backward(x, h, W1, W2)
+        ctx.save_for_backward(x, h, W1, W2, b1)
         ctx.signs = signs
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, h, W1, W2 = ctx.saved_tensors
+        x, h, W1, W2, b1 = ctx.saved_tensors
         dres = _residual_grad(dy)
         dy = dy.contiguous()
         dres = _unalias(dres, dy)
@@ -390,7 +422,7 @@ class FFNFn(torch.autograd.Function):
         db2 = _bias_grad(dy, T, d)
         dx = _input_grad(dh, F, (W1,), T, d, x.dtype, add_to=dres)  # accumulates into dres in place
         dW1 = _weight_grad(dh, x, W1, T, ctx.needs_input_grad[1])
-        db1 = L.colsum(dh, T, F, F)
+        db1 = _colsum_overlapped(dh, T, F, F, (b1,))
         return dx, dW1, db1, dW2, db2
 
 
@@ -434,7 +466,7 @@ class MHAFn(torch.autograd.Function):
                    dense_mask=cfg["dense_mask"], causal=cfg["causal"], p_drop=cfg["p_attn"], seed=seed, P_out=P,
                    q_off=cfg.get("q_off"), k_off=cfg.get("k_off"))
         out = L.gemm(L.GEMM_NT, O, compute_weight(Wo, dt), Tq, d, nv, nv, nv, bias=bo.detach())
-        ctx.save_for_backward(q_in, kv_in, Q, K, V, O, lse, Wq, Wk, Wv, Wo)
+        ctx.save_for_backward(q_in, kv_in, Q, K, V, O, lse, Wq, Wk, Wv, Wo, bq, bk, bv)
         ctx.cfg, ctx.seed, ctx.lds = cfg, seed, (ldq, ldk, ldv)
         if P is not None:
             ctx.mark_non_differentiable(P)
@@ -442,7 +474,7 @@ class MHAFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout, _dP):
-        q_in, kv_in, Q, K, V, O, lse, Wq, Wk, Wv, Wo = ctx.saved_tensors
+        q_in, kv_in, Q, K, V, O, lse, Wq, Wk, Wv, Wo, bq, bk, bv = ctx.saved_tensors
         cfg = ctx.cfg
         B, Lq, Lk, H, dk, dv = cfg["B"], cfg["Lq"], cfg["Lk"], cfg["H"], cfg["dk"], cfg["dv"]
         dt, dev = q_in.dtype, q_in.device
@@ -484,19 +516,19 @@ class MHAFn(torch.autograd.Function):
             else:
                 dW = L.gemm(L.GEMM_TN, dqkv, q_in, n3, d, Tq, lddq, q_in.stride(0), out_dtype=f32)
                 dWq, dWk, dWv = dW[:nq], dW[nq:nq + nk], dW[nq + nk:]
-            db = L.colsum(dqkv, Tq, n3, lddq)
+            db = _colsum_overlapped(dqkv, Tq, n3, lddq, (bq, bk, bv))
             dbq, dbk, dbv = db[:nq], db[nq:nq + nk], db[nq + nk:]
             dq_in = _input_grad(dqkv, lddq, (Wq, Wk, Wv), Tq, d, dt, add_to=dres)  # accumulates into dres in place
             dkv_in = None
         else:
             dWq = _weight_grad(dQ, q_in, Wq, Tq, need[2])
-            dbq = L.colsum(dQ, Tq, nq, lddq)
+            dbq = _colsum_overlapped(dQ, Tq, nq, lddq, (bq,))
             if batched:
                 dWk, dWv = _weight_grad(dK, kv_in, Wk, Tk, need[4]), _weight_grad(dV, kv_in, Wv, Tk, need[6])
             else:
                 dW = L.gemm(L.GEMM_TN, dkv, kv_in, nk + nv, d, Tk, lddk, kv_in.stride(0), out_dtype=f32)
                 dWk, dWv = dW[:nk], dW[nk:]
-            db = L.colsum(dkv, Tk, nk + nv, lddk)
+            db = _colsum_overlapped(dkv, Tk, nk + nv, lddk, (bk, bv))
             dbk, dbv = db[:nk], db[nk:]
             dq_in = _input_grad(dQ, lddq, (Wq,), Tq, d, dt, add_to=dres)  # accumulates into dres in place
             dkv_in = _input_grad(dkv, lddk, (Wk, Wv), Tk, d, dt)
