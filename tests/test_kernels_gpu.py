@@ -723,3 +723,38 @@ def test_device_collate_matches_host_collate(L):
         assert torch.equal(a, b.cpu())
     one = device_collate_fn([[2, 3]])
     assert one[0].tolist() == [[2, 3]] and one[1].tolist() == [[1, 2]]
+
+
+def test_full_size_generator_and_loss_kernels(L):
+    """The two largest launches of the training step at their benchmark size (25 639 x 35 000, K = 512, bf16):
+    sampled rows of the generator product against an fp32 matmul of the same rows, and properties of the fused
+    loss kernel that hold for any input — every gradient row sums to zero (softmax and the smoothed target
+    both sum to one), pad rows are zero, the counts are exact, in place equals out of place."""
+    g = torch.Generator(device=DEV).manual_seed(3)
+    T, V, d = 25639, 35000, 512
+    x = (torch.randn(T, d, device=DEV, generator=g) * 0.5).to(torch.bfloat16)
+    W = (torch.randn(V, d, device=DEV, generator=g) * 0.05).to(torch.bfloat16)
+    logits = L.gemm(L.GEMM_NT, x, W, T, V, d, d, d)
+    rows = torch.randint(0, T, (48,), device=DEV, generator=g)
+    rows[0], rows[1] = 0, T - 1
+    ref = x[rows].float() @ W.float().t()
+    assert rel_err(logits[rows].float(), ref) <= BF16_RTOL / 4
+    gold = torch.randint(1, V, (T,), device=DEV, generator=g)
+    gold[::9] = 0
+    stats = torch.zeros(3, dtype=torch.float64, device=DEV)
+    dl = torch.empty_like(logits)
+    L.xent_fwd_bwd(logits, gold, dl, stats, 1.0, 0.1, 0)
+    n_real = int((gold != 0).sum())
+    assert int(stats[2].item()) == n_real and 0 <= int(stats[1].item()) <= n_real
+    assert stats[0].item() > 0 and abs(stats[0].item() / n_real - np.log(V)) < 1.0  # near-uniform predictions
+    row_sums = dl.float().sum(1)
+    assert row_sums.abs().max().item() <= 2e-3  # 35 000 bf16 roundings of values around 3e-5
+    assert dl[gold == 0].abs().max().item() == 0
+    lse = torch.logsumexp(logits[rows].float(), 1, keepdim=True)
+    q = torch.full((48, V), 0.1 / (V - 1), device=DEV)
+    q[torch.arange(48, device=DEV), gold[rows]] = 0.9
+    ref_g = (torch.exp(logits[rows].float() - lse) - q) * (gold[rows] != 0)[:, None]
+    assert rel_err(dl[rows].float(), ref_g) <= BF16_RTOL
+    stats2 = torch.zeros(3, dtype=torch.float64, device=DEV)
+    L.xent_fwd_bwd(logits, gold, logits, stats2, 1.0, 0.1, 0)
+    assert torch.equal(logits, dl) and stats2[1].item() == stats[1].item() and stats2[2].item() == stats[2].item()
