@@ -758,3 +758,28 @@ def test_full_size_generator_and_loss_kernels(L):
     stats2 = torch.zeros(3, dtype=torch.float64, device=DEV)
     L.xent_fwd_bwd(logits, gold, logits, stats2, 1.0, 0.1, 0)
     assert torch.equal(logits, dl) and stats2[1].item() == stats[1].item() and stats2[2].item() == stats[2].item()
+
+
+@pytest.mark.parametrize("causal", [False, True])
+def test_full_size_attention_sampled_sentences(L, causal):
+    """Fused attention forward / backward at the benchmark shape (640 sentences x 50 positions x 8 heads x 64,
+    bf16, lengths 28..50): sentences do not interact, so a sample of them is checked against the fp64 oracle
+    run on those sentences alone."""
+    g = torch.Generator().manual_seed(17)
+    B, Lq, H, dk = 640, 50, 8, 64
+    lens = torch.randint(28, 51, (B,), generator=g)
+    lens[0], lens[1] = 50, 28
+    keypad = torch.arange(Lq)[None, :] >= lens[:, None]
+    q, k, v, do = (rnd((B, Lq, H, dk), torch.bfloat16, g) for _ in range(4))
+    o, _, _, bwd = run_attn(L, q, k, v, keypad, causal, torch.bfloat16)
+    pick = torch.tensor([0, 1, 2, 317, 638, 639])
+    ro, _, rbwd = oracle_attn(q[pick].float(), k[pick].float(), v[pick].float(), keypad[pick], causal)
+    live = (~keypad[pick])[:, :, None, None]  # query rows past a sentence's end are padding: not compared
+    assert rel_err(o.cpu()[pick].float() * live, ro * live) <= BF16_RTOL
+    do_live = do.clone()  # padding query rows get no upstream gradient, as after the pad-row zeroing of the layers
+    do_live[keypad] = 0
+    dq, dk_, dv_ = bwd(do_live)
+    rdq, rdk, rdv = rbwd(do_live[pick].float())
+    assert rel_err(dq.cpu()[pick].float() * live, rdq * live) <= BF16_RTOL
+    assert rel_err(dk_.cpu()[pick].float(), rdk) <= BF16_RTOL
+    assert rel_err(dv_.cpu()[pick].float(), rdv) <= BF16_RTOL
