@@ -783,3 +783,61 @@ def test_full_size_attention_sampled_sentences(L, causal):
     assert rel_err(dq.cpu()[pick].float() * live, rdq * live) <= BF16_RTOL
     assert rel_err(dk_.cpu()[pick].float(), rdk) <= BF16_RTOL
     assert rel_err(dv_.cpu()[pick].float(), rdv) <= BF16_RTOL
+
+
+def test_full_size_weight_gradients_layernorm_and_adam(L):
+    """The remaining large launches of the training step at their benchmark size (25 639 token rows, d = 512,
+    F = 2048): one grouped launch with the weight-gradient products of a decoder layer (contraction over all
+    rows, written and accumulated), the fused residual + LayerNorm forward / backward over all rows, and one
+    Adam launch over a 17.9 M-element and a 1 M-element tensor — each against a plain torch computation in
+    fp32 / fp64 on the same operands."""
+    g = torch.Generator(device=DEV).manual_seed(23)
+    T, d, F = 25639, 512, 2048
+    rn = lambda *shape, s=1.0: (torch.randn(shape, device=DEV, generator=g) * s).to(torch.bfloat16)
+    # grouped weight gradients
+    x, dqkv, h, dh, dy = rn(T, d), rn(T, 3 * d), rn(T, F), rn(T, F), rn(T, d)
+    probs, refs = [], []
+    for A, B_, acc in ((dqkv[:, :d], x, False), (dqkv[:, d:2 * d], x, True), (dqkv[:, 2 * d:], x, False), (dy, x, False),
+                       (dh, x, True), (dy, h, False)):
+        M, N = A.shape[1], B_.shape[1]
+        C = torch.randn((M, N), device=DEV, generator=g) if acc else torch.full((M, N), float("nan"), device=DEV)
+        refs.append((C, (C.double() if acc else 0) + A.double().t() @ B_.double()))
+        probs.append((A, B_, C, M, N, T, A.stride(0), B_.stride(0), N, acc))
+    L.gemm_grouped_tn(probs)
+    for i, (C, ref) in enumerate(refs):
+        assert rel_err(C, ref) <= 2e-5, i
+    # residual + LayerNorm
+    gamma = 1 + 0.1 * torch.randn(d, device=DEV, generator=g)
+    beta = 0.1 * torch.randn(d, device=DEV, generator=g)
+    pad = (torch.rand(T, device=DEV, generator=g) < 0.1)
+    res = rn(T, d)
+    y, mean, rstd = L.add_ln_fwd(x, res, gamma, beta, pad.to(torch.uint8), 1e-5, 0.0, 0)
+    xr, rr = x.double().requires_grad_(True), res.double().requires_grad_(True)
+    gr, br = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    ref = torch.nn.functional.layer_norm(xr + rr, (d,), gr, br, 1e-5) * (~pad)[:, None]
+    assert rel_err(y, ref) <= BF16_RTOL and (y[pad] == 0).all()
+    ref.backward(dy.double())
+    dx, dres, dg, db = L.add_ln_bwd(dy, x, res, gamma, pad.to(torch.uint8), mean, rstd, 0.0, 0)
+    assert rel_err(dres, rr.grad) <= BF16_RTOL
+    assert rel_err(dg, gr.grad) <= 5e-3 and rel_err(db, br.grad) <= 5e-3
+    # Adam, two steps
+    ps = [torch.randn(35000, d, device=DEV, generator=g), torch.randn(F, d, device=DEV, generator=g)]
+    gs = [torch.randn(p.shape, device=DEV, generator=g) * 1e-3 for p in ps]
+    ref_p = [p.double().clone() for p in ps]
+    ref_m = [torch.zeros_like(p) for p in ref_p]
+    ref_v = [torch.zeros_like(p) for p in ref_p]
+    ms, vs = [torch.zeros_like(p) for p in ps], [torch.zeros_like(p) for p in ps]
+    copies = [torch.empty(p.shape, dtype=torch.bfloat16, device=DEV) for p in ps]
+    tab = lambda ts: torch.tensor([t.data_ptr() for t in ts], dtype=torch.int64, device=DEV)
+    tables = {"p": tab(ps), "g": tab(gs), "m": tab(ms), "v": tab(vs), "b": tab(copies),
+              "n": torch.tensor([p.numel() for p in ps], dtype=torch.int64, device=DEV)}
+    b1, b2, eps, lr = 0.9, 0.98, 1e-9, 3e-4
+    for step in (1, 2):
+        L.adam_multi(tables, 2, max(p.numel() for p in ps), lr, b1, b2, eps, step)
+        for p, gg, m_, v_ in zip(ref_p, gs, ref_m, ref_v):
+            m_.mul_(b1).add_(gg.double(), alpha=1 - b1)
+            v_.mul_(b2).addcmul_(gg.double(), gg.double(), value=1 - b2)
+            p.addcdiv_(m_ / (1 - b1 ** step), (v_ / (1 - b2 ** step)).sqrt() + eps, value=-lr)
+    for p, rp, c in zip(ps, ref_p, copies):
+        assert rel_err(p, rp) <= 1e-6
+        assert torch.equal(c, p.to(torch.bfloat16))
