@@ -223,3 +223,39 @@ def test_style_step_bf16_close_to_fp32():
     a, b = res[torch.float32], res[torch.bfloat16]
     assert abs(a[0] - b[0]) <= BF16 * a[0] and abs(a[1] - b[1]) <= BF16 * a[1]
     assert (a[2] - b[2]).norm() <= 0.15 * a[2].norm()
+
+
+def test_full_size_classifier_path_packed_equals_padded():
+    """The classifier path at the benchmark shape (640 sentences, 49 target positions, d = 512, vocabulary
+    35 000, the reference's classifier defaults: 300-wide embeddings, 100 filters of 5 steps, 50-step window),
+    bf16: decoder rows held without padding give the same verdicts as the padded batch, and the per-sentence
+    outputs of a sample of sentences match an fp64 evaluation of those sentences alone."""
+    from oracle import style_np as S
+    from specialk_amd.classifier.CNNModels import ConvNet
+    torch.manual_seed(4)
+    B, Lt, d, V = 640, 49, 512, 35000
+    gen = torch.Generator().manual_seed(6)
+    opt = Namespace(num_filters=100, filter_size=5, sequence_length=50, word_vec_size=300, dropout=0.2, num_classes=2)
+    cnn = ConvNet(opt, V).to(DEV).eval()
+    cnn.compute_dtype = torch.bfloat16
+    with torch.no_grad():
+        cnn.linear.weight.mul_(3.0)
+    class_input = torch.nn.Sequential(torch.nn.Linear(d, V)).to(DEV)
+    with torch.no_grad():
+        class_input[0].weight.mul_(8.0)  # peaked distributions: the verdicts spread out
+    lens = torch.randint(27, Lt + 1, (B,), generator=gen)
+    lens[0], lens[1] = Lt, 27
+    dec = torch.randn(B, Lt, d, generator=gen)
+    dec[torch.arange(Lt)[None, :] >= lens[:, None]] = 0  # the decoder leaves pad rows zero
+    dec = dec.to(torch.bfloat16).to(DEV)
+    loss_pad, y_pad = cnn.loss_from_decoder(dec.reshape(B * Lt, d), B, Lt, class_input, 1)
+    packed = torch.cat([dec[b, :n] for b, n in enumerate(lens.tolist())])
+    off = torch.tensor(np.concatenate([[0], np.cumsum(lens.numpy())]), dtype=torch.int32, device=DEV)
+    loss_pk, y_pk = cnn.loss_from_decoder(packed, B, Lt, class_input, 1, off=off)
+    assert torch.equal(y_pad, y_pk) and torch.equal(loss_pad, loss_pk)  # same rows, same kernels, same order
+    assert 0.02 < y_pad.std().item() and 0 < loss_pad.item() < 5
+    pick = [0, 1, 333, 639]
+    w = {k: v.detach().double().cpu().numpy() for k, v in cnn.state_dict().items()}
+    _, y_ref = S.classifier_loss(dec[pick].double().cpu().numpy(), class_input[0].weight.detach().double().cpu().numpy(),
+                                 class_input[0].bias.detach().double().cpu().numpy(), w, 50, 5, 1)
+    close(y_pad[pick], y_ref, BF16, what="classifier outputs of sampled sentences")
