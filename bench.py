@@ -319,12 +319,14 @@ def main():
         }
     if dist_on:
         dist.barrier()
-    if rank == 0 and world == 1:
+    if rank == 0:
+        # rank 0 alone, after the timed region: local steps without the gradient exchange (the other ranks wait
+        # at the barrier below), so the figure is the per-GPU kernel efficiency at every N
         if not args.no_roofline and args.dtype == "bf16":
             out["roofline"] = gemm_roofline(m, opt, batches[0], 3)
             if args.config != "cfg2" or args.padded:  # the counter passes were taken on the default workload
                 out["roofline"]["traffic"] = out["roofline"]["traffic_source"] = None
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(cfg)
     if rank == 0:
         sys.stdout.flush()
