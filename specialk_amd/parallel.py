@@ -12,6 +12,13 @@ has been accumulated, on RCCL's own stream while backward continues.  Bucket siz
 point-to-point (7 links x ~153 GB/s per GPU) and RCCL's ring moves 2(N-1)/N of the bucket over
 one link pair per step, so buckets must be large enough (tens of MB) to reach link bandwidth
 yet small enough that the last bucket's exposed tail stays short.
+
+One-dimensional parameters (biases, LayerNorm gains and offsets: 156 of them in a 6+6 Transformer) are
+handled differently from matrices: while a bucket view is attached as .grad, autograd ADDS every new
+gradient into it with a kernel of its own (~5 us each, 0.8 ms per step).  Their .grad is therefore left
+empty during backward — autograd then adopts the freshly computed tensor without a kernel — and when
+their bucket is complete all of them are copied into it by one multi-tensor copy, after which .grad is
+the bucket view again.
 """
 import torch
 import torch.distributed as dist
@@ -58,17 +65,39 @@ class GradBucketReducer:
 
     def _close(self, plist, n):
         flat = torch.zeros(n, dtype=torch.float32, device=plist[0].device)
-        off = 0
-        for p in plist:
-            p.grad = flat[off:off + p.numel()].view(p.shape)
-            off += p.numel()
         self.buckets.append((flat, list(plist)))
+        self._reattach(flat, plist)
+
+    @staticmethod
+    def _late(p):
+        """Gradients that autograd produces as small tensors of their own (see the module docstring)."""
+        return p.dim() == 1
+
+    def _gather_late(self, bi):
+        """Copy the adopted gradients of the bucket's one-dimensional parameters into the bucket."""
+        flat, plist = self.buckets[bi]
+        views, grads, off = [], [], 0
+        for p in plist:
+            n = p.numel()
+            if self._late(p) and p.grad is not None and p.grad.data_ptr() != flat.data_ptr() + 4 * off:
+                views.append(flat[off:off + n].view(p.shape))
+                grads.append(p.grad)
+            off += n
+        if views:
+            torch._foreach_copy_(views, grads)
+            off = 0
+            for p in plist:
+                n = p.numel()
+                if self._late(p) and p.grad is not None:
+                    p.grad = flat[off:off + n].view(p.shape)
+                off += n
 
     def _make_hook(self, bi):
         def hook(_p):
             self._pending[bi] -= 1
             if self._pending[bi] == 0:
                 flat = self.buckets[bi][0]
+                self._gather_late(bi)
                 self._handles.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         return hook
 
@@ -84,17 +113,17 @@ class GradBucketReducer:
         for bi, (flat, plist) in enumerate(self.buckets):
             flat.zero_()
             self._pending[bi] = len(plist)
-            for p in plist:  # a foreign zero_grad(set_to_none=True) may have detached the view
-                if p.grad is None or p.grad.data_ptr() < flat.data_ptr() or \
-                        p.grad.data_ptr() >= flat.data_ptr() + flat.numel() * 4:
-                    self._reattach(flat, plist)
-                    break
+            self._reattach(flat, plist)  # also repairs views a foreign zero_grad(set_to_none=True) detached
         self._handles = []
 
     def _reattach(self, flat, plist):
+        """Matrices get their bucket view as .grad; one-dimensional parameters start the step without one."""
         off = 0
         for p in plist:
-            p.grad = flat[off:off + p.numel()].view(p.shape)
+            if self._late(p) and self.active:
+                p.grad = None
+            elif p.grad is None or p.grad.data_ptr() != flat.data_ptr() + 4 * off:
+                p.grad = flat[off:off + p.numel()].view(p.shape)
             off += p.numel()
 
     def finish(self):
@@ -102,6 +131,7 @@ class GradBucketReducer:
         step (unused parameters) are reduced here so that all ranks stay in lock-step."""
         if self._staged:
             for bi, (flat, _) in enumerate(self.buckets):
+                self._gather_late(bi)
                 host = flat.cpu()
                 dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
                 flat.copy_(host)
@@ -109,10 +139,18 @@ class GradBucketReducer:
         elif self.active:
             for bi, (flat, _) in enumerate(self.buckets):
                 if self._pending[bi] > 0:
+                    self._gather_late(bi)
                     self._handles.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
                     self._pending[bi] = 0
             for h in self._handles:
                 h.wait()
+        if self.active:  # one-dimensional parameters that got no gradient this step read as zero, like the rest
+            for flat, plist in self.buckets:
+                off = 0
+                for p in plist:
+                    if p.grad is None:
+                        p.grad = flat[off:off + p.numel()].view(p.shape)
+                    off += p.numel()
         self._handles = []
 
 
