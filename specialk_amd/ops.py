@@ -178,11 +178,14 @@ def _colsum_overlapped(dy, T, N, ld, biases):
     """Column sums of dy (T, N; row stride ld) = the gradients of `biases` (the parameters the result is
     split over).  Inside batched_weight_grads() on a single GPU the HBM-bound reduction runs on a second
     stream beside the latency-bound input-gradient GEMMs of the main stream; the context joins the streams
-    when it exits, before anything reads a gradient.  Not taken when a reducer consumes gradients during
-    backward (on_ready) or when a bias already holds a gradient (autograd would then add to it on the main
-    stream straight away)."""
+    when it exits, before anything reads a gradient.  Not taken when a bias already holds a gradient (autograd
+    would then add to it on the main stream straight away), nor when a reducer consumes gradients during
+    backward (on_ready) unless it declares `joins_side_stream` — that it calls join_side_stream() before it
+    reads gradients that autograd handed to it."""
     b = _wgrad_batch
-    if b is None or b.on_ready is not None or not b.overlap or any(p.grad is not None for p in biases):
+    reducer = getattr(b.on_ready, "__self__", None) if b is not None and b.on_ready is not None else None
+    if b is None or not b.overlap or any(p.grad is not None for p in biases) or \
+            (b.on_ready is not None and not getattr(reducer, "joins_side_stream", False)):
         return L.colsum(dy, T, N, ld)
     main = torch.cuda.current_stream(dy.device)
     side = _side_streams.get(dy.device)
@@ -196,6 +199,13 @@ def _colsum_overlapped(dy, T, N, ld, biases):
     out.record_stream(side)
     b.side = side
     return out
+
+
+def join_side_stream():
+    """Make the current stream wait for the bias-gradient reductions issued so far on the second stream."""
+    b = _wgrad_batch
+    if b is not None and b.side is not None:
+        torch.cuda.current_stream().wait_stream(b.side)
 
 
 def _residual_grad(dy):

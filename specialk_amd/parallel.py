@@ -31,6 +31,7 @@ class GradBucketReducer:
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.active = self.world > 1 or (always_reduce and dist.is_initialized())
+        self.joins_side_stream = True  # see ops._colsum_overlapped: _gather_late joins before it reads
         self.params = [p for p in params if p.requires_grad]
         seen, uniq = set(), []
         for p in self.params:
@@ -84,6 +85,9 @@ class GradBucketReducer:
                 grads.append(p.grad)
             off += n
         if views:
+            if views[0].is_cuda:
+                from . import ops
+                ops.join_side_stream()  # bias gradients may still be in flight on the second stream
             torch._foreach_copy_(views, grads)
             off = 0
             for p in plist:
