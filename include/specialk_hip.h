@@ -87,6 +87,17 @@ int skhip_gemm_grouped_tn(const int64_t* problems, int n, void* workspace, int64
 int skhip_colsum(const void* X, float* out, int64_t M, int64_t N, int64_t ldx, int accumulate,
                  int dtype, void* workspace, int64_t workspace_bytes, void* stream);
 
+/* skhip_colsum without a workspace argument and without any allocation.  No counterpart in the
+ * reference: it exists for callers that cannot allocate device memory (code under HIP graph capture,
+ * tight serving loops, harnesses that forbid hipMalloc).  The chunk partials go to a 2 MiB array built
+ * into the library's code object (one copy per GPU, held until the process ends), so N is limited to
+ * SK_COLSUM_NOALLOC_MAX_N; larger N returns SK_ERR_ARG.  Results are bit-identical to skhip_colsum
+ * called with a 2 MiB workspace.  All calls on one GPU share the array: calls that overlap in time on
+ * one GPU (different streams) race; calls on one stream do not.                                   */
+#define SK_COLSUM_NOALLOC_MAX_N 65536
+int skhip_colsum_noalloc(const void* X, float* out, int64_t M, int64_t N, int64_t ldx, int accumulate,
+                         int dtype, void* stream);
+
 /* ---- attention ----------------------------------------------------------------------
  * Replaces ScaledDotProductAttention.forward (lib/transformer/Modules.py:17-28) together
  * with the head split / merge copies and the h-fold mask repeat of MultiHeadAttention

@@ -19,7 +19,7 @@ LIB_PATH = os.path.join(_HERE, "libspecialk_hip.so")
 
 # every symbol include/specialk_hip.h declares
 EXPORTS = [
-    "skhip_version", "skhip_last_error", "skhip_init", "skhip_gemm", "skhip_gemm_grouped_tn", "skhip_colsum", "skhip_attn_fwd",
+    "skhip_version", "skhip_last_error", "skhip_init", "skhip_gemm", "skhip_gemm_grouped_tn", "skhip_colsum", "skhip_colsum_noalloc", "skhip_attn_fwd",
     "skhip_attn_bwd", "skhip_attn_varlen_fwd", "skhip_attn_varlen_bwd", "skhip_add_ln_fwd", "skhip_add_ln_bwd_ws_floats", "skhip_add_ln_bwd", "skhip_embed_fwd",
     "skhip_embed_bwd", "skhip_pack_plan", "skhip_xent_fwd_bwd", "skhip_adam_multi", "skhip_cast_multi", "skhip_cast2d_multi", "skhip_convert",
     "skhip_decode_attn", "skhip_beam_topk_ws_bytes", "skhip_beam_topk", "skhip_gather_rows",
@@ -53,6 +53,7 @@ def load():
     lib.skhip_gemm.argtypes = [c_int, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_f32,
                                c_int, c_int, c_int, c_p, c_i64, c_p]
     lib.skhip_colsum.argtypes = [c_p, c_p, c_i64, c_i64, c_i64, c_int, c_int, c_p, c_i64, c_p]
+    lib.skhip_colsum_noalloc.argtypes = [c_p, c_p, c_i64, c_i64, c_i64, c_int, c_int, c_p]
     lib.skhip_attn_fwd.argtypes = [c_p] * 8 + [c_int] * 6 + [c_i64] * 4 + [c_f32, c_int, c_f32, c_u64, c_int, c_p]
     lib.skhip_attn_bwd.argtypes = [c_p] * 12 + [c_int] * 6 + [c_i64] * 7 + [c_f32, c_int, c_f32, c_u64, c_int, c_p]
     lib.skhip_attn_varlen_fwd.argtypes = [c_p] * 7 + [c_int] * 6 + [c_i64] * 4 + [c_f32, c_int, c_f32, c_u64, c_int, c_p]
@@ -165,6 +166,14 @@ def colsum(X, M, N, ldx, out=None, accumulate=False):
     ws = workspace()
     _check(lib.skhip_colsum(_ptr(X), _ptr(out), M, N, ldx, int(accumulate), dcode(X.dtype), _ptr(ws), ws.numel(),
                             _stream()), "skhip_colsum")
+    return out
+
+
+def colsum_noalloc(X, M, N, ldx, out, accumulate=False):
+    """skhip_colsum with the partial sums in the library's built-in per-GPU scratch array: the call allocates
+    nothing (out is the caller's).  Calls that overlap on one GPU race on that array."""
+    _check(load().skhip_colsum_noalloc(_ptr(X), _ptr(out), M, N, ldx, int(accumulate), dcode(X.dtype), _stream()),
+           "skhip_colsum_noalloc")
     return out
 
 

@@ -41,6 +41,7 @@
 #include <algorithm>
 #include <vector>
 #include <stdlib.h>
+#include <mutex>
 
 namespace {
 
@@ -1456,4 +1457,50 @@ extern "C" int skhip_colsum(const void* X, float* out, int64_t M, int64_t N, int
     SK_CHECK_LAUNCH("skhip_colsum(finish)");
   }
   return SK_OK;
+}
+
+// ---- column sums for callers that cannot allocate (HIP graph capture, serving loops, harnesses that
+// forbid hipMalloc): the chunk partials live in a file-scope device array instead of a caller workspace.
+// Every GPU holds its own copy of the array at its own address; the address is looked up once per
+// device (hipGetSymbolAddress with that device current) and only that pointer is ever handed to
+// kernels.  Every partial that the finishing kernel reads has been written by the first kernel of the
+// same call, so nothing has to be cleared between calls; two calls that overlap on one GPU (different
+// streams) would share the array and race.
+constexpr int64_t kColsumScratchFloats = 512 * 1024;  // 2 MiB per GPU, held until the process ends
+static __device__ __align__(256) float g_colsum_scratch[kColsumScratchFloats];
+constexpr int kMaxDevices = 64;
+static float* g_colsum_scratch_ptr[kMaxDevices];  // per device; nullptr until looked up
+static std::mutex g_colsum_scratch_mutex;
+
+// Device address of the current device's copy of the scratch array (looked up on first use).
+int sk_colsum_scratch(float** ptr) {
+  int dev = -1;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess || dev < 0 || dev >= kMaxDevices) {
+    sk_set_error("skhip_colsum_noalloc: no usable current device (%s)", e == hipSuccess ? "index out of range" : hipGetErrorString(e));
+    return SK_ERR_LAUNCH;
+  }
+  std::lock_guard<std::mutex> lock(g_colsum_scratch_mutex);
+  if (!g_colsum_scratch_ptr[dev]) {
+    void* p = nullptr;
+    e = hipGetSymbolAddress(&p, HIP_SYMBOL(g_colsum_scratch));
+    if (e != hipSuccess || !p) {
+      sk_set_error("skhip_colsum_noalloc: hipGetSymbolAddress failed on device %d: %s", dev, hipGetErrorString(e));
+      return SK_ERR_LAUNCH;
+    }
+    g_colsum_scratch_ptr[dev] = (float*)p;
+  }
+  *ptr = g_colsum_scratch_ptr[dev];
+  return SK_OK;
+}
+
+extern "C" int skhip_colsum_noalloc(const void* X, float* out, int64_t M, int64_t N, int64_t ldx, int accumulate,
+                                    int dtype, void* stream_) {
+  SK_CHECK_ARG(N > 0 && N <= SK_COLSUM_NOALLOC_MAX_N,
+               "skhip_colsum_noalloc: N = %lld is outside 1..%d (the built-in scratch holds %lld floats of partial sums)",
+               (long long)N, SK_COLSUM_NOALLOC_MAX_N, (long long)kColsumScratchFloats);
+  float* scratch = nullptr;
+  int rc = sk_colsum_scratch(&scratch);
+  if (rc) return rc;
+  return skhip_colsum(X, out, M, N, ldx, accumulate, dtype, scratch, kColsumScratchFloats * 4, stream_);
 }

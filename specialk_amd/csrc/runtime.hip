@@ -28,7 +28,8 @@ int sk_num_cus() {
 
 extern "C" int skhip_init(void) {
   sk_num_cus();
-  return SK_OK;
+  float* scratch = nullptr;
+  return sk_colsum_scratch(&scratch);  // the current device's copy of skhip_colsum_noalloc's scratch array
 }
 extern "C" const char* skhip_version(void) { return "specialk_hip 0.1 (gfx950)"; }
 extern "C" const char* skhip_last_error(void) { return g_err; }
