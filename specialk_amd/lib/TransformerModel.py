@@ -23,6 +23,7 @@ from collections import OrderedDict
 import torch
 import torch.nn as nn
 
+from ..core.serialization import load_trusted_types_only
 from .. import ops
 from ..optim import FusedAdam
 from ..parallel import GradBucketReducer, all_reduce_scalars
@@ -82,7 +83,7 @@ class TransformerModel(NMTModel):
         """Load encoder (and decoder + generator) checkpoints; saved settings override `opt`
         except for run-specific fields (lib/TransformerModel.py:77-153)."""
         if encoder_path:
-            enc = torch.load(encoder_path, map_location="cpu", weights_only=False)
+            enc = load_trusted_types_only(encoder_path, "an encoder checkpoint")
             enc["model"] = _strip_module_prefix(enc["model"])
             saved = enc["settings"]
             for arg in dir(saved):
@@ -94,7 +95,7 @@ class TransformerModel(NMTModel):
             if self.opt.verbose:
                 print("[Info] Loaded encoder model.")
         if decoder_path:
-            dec = torch.load(decoder_path, map_location="cpu", weights_only=False)
+            dec = load_trusted_types_only(decoder_path, "a decoder checkpoint")
             dec["model"] = _strip_module_prefix(dec["model"])
             self.model.decoder.load_state_dict(dec["model"])
             self.model.generator.load_state_dict(dec["generator"])

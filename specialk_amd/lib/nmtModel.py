@@ -20,6 +20,7 @@ import torch.utils.data
 
 from ..core import constants
 from ..core.bpe import Encoder as BPE
+from ..core.serialization import load_trusted_types_only
 from ..core.dataset import (TokenBudgetBatchSampler, TranslationDataset, collate_fn, paired_collate_fn,
                             paired_device_collate_fn)
 
@@ -151,7 +152,7 @@ class NMTModel:
     def load_dataset(self):
         """Loads the pickled dataset written by the reference's preprocess.py:
         {settings, dict: {src, tgt}, train: {src, tgt}, valid: {src, tgt}}."""
-        data = torch.load(self.opt.data, weights_only=False)
+        data = load_trusted_types_only(self.opt.data, "a dataset file")
         self.dataset_settings = data["settings"]
         self.opt.max_token_seq_len = data["settings"].max_token_seq_len
         if "byte_pairs" in data["dict"]["src"] and "__sow" in data["dict"]["src"]["byte_pairs"]:
@@ -193,7 +194,7 @@ class NMTModel:
 
     def load_testdata(self, test_datapath, test_vocab):
         """Text file + dataset vocabulary -> (DataLoader of (seq, pos), max_token_seq_len, is_bpe, decoder)."""
-        data = torch.load(test_vocab, weights_only=False)
+        data = load_trusted_types_only(test_vocab, "a dataset (vocabulary) file")
         settings = data["settings"]
         is_bpe = str(getattr(settings, "format", "word")).lower() == "bpe"
         override = getattr(self.opt, "override_max_token_seq_len", None)

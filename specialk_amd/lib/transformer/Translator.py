@@ -4,6 +4,7 @@ and `.max_token_seq_len`, and translate_batch(src_seq, src_pos) -> (hypotheses, 
 import torch
 import torch.nn as nn
 
+from ...core.serialization import load_trusted_types_only
 from ...decode import BeamDecoder
 from .Models import Transformer
 
@@ -18,7 +19,7 @@ class Translator(object):
         else:
             self.device = torch.device("cuda")  # this package has no CPU path
         if new:
-            checkpoint = torch.load(opt.model, map_location="cpu", weights_only=False)
+            checkpoint = load_trusted_types_only(opt.model, "a model checkpoint")
             model_opt = checkpoint["settings"]
             self.model_opt = model_opt
             self.max_token_seq_len = model_opt.max_token_seq_len
