@@ -124,7 +124,7 @@ def derived_weight(kind, params):
             rows.append((p.data_ptr(), d.tensor.data_ptr() + off * esz, R, C, total, 1))
             off += R
     d.rows = rows
-    d.refs = [weakref.ref(p) for p in params]
+    d.refs = [weakref.ref(p, lambda _r, k=key: _drop_derived(k)) for p in params]
     d.versions = [p._version for p in params]
     d.ptrs = [p.data_ptr() for p in params]
     if any(q != r[0] for q, r in zip(d.ptrs, rows)):
@@ -132,6 +132,15 @@ def derived_weight(kind, params):
     _launch_cast2d(_tables_of(rows, dev))
     _derived_tables = None  # pointers may have changed
     return d.tensor
+
+
+def _drop_derived(key):
+    """A master parameter of the copy `key` was freed: forget the copy and the device tables that still
+    hold its (now dangling) source pointers, so the next refresh neither reads freed memory nor keeps the
+    orphaned copy alive."""
+    global _derived_tables
+    _derived.pop(key, None)
+    _derived_tables = None
 
 
 def _tables_of(rows, dev):
@@ -208,10 +217,27 @@ def join_side_stream():
         torch.cuda.current_stream().wait_stream(b.side)
 
 
+_pending_dres = {}  # data_ptr of a gradient whose residual part AddLNFn.backward handed on -> not yet picked up
+
+
 def _residual_grad(dy):
     """The residual-branch gradient that AddLNFn.backward attached to dy (see there), or None."""
     pre = getattr(dy, "_sk_dres", None)
-    return pre[1] if pre is not None and pre[0] == dy.data_ptr() else None
+    if pre is not None and pre[0] == dy.data_ptr():
+        _pending_dres.pop(pre[0], None)
+        return pre[1]
+    return None
+
+
+def _check_residual_handoff():
+    """AddLNFn.backward hands the residual-branch gradient to the backward of the sub-layer that runs next by
+    attaching it to the gradient tensor.  If that tensor object was replaced on the way (a copy, a hook), the
+    sub-layer would not see it and the gradient would silently lose a term: fail instead."""
+    if _pending_dres:
+        _pending_dres.clear()
+        raise RuntimeError("a residual-branch gradient handed over by AddLNFn.backward was not picked up by the "
+                           "following sub-layer's backward (the gradient tensor was replaced on the way); "
+                           "call add_ln(..., res_feeds_x=False) for this graph")
 
 
 def _w2d(w):
@@ -597,6 +623,7 @@ class AddLNFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x, res, gamma, mean, rstd = ctx.saved_tensors
+        _check_residual_handoff()
         dx, dres, dg, db, dxs = L.add_ln_bwd(dy.contiguous(), x, res, gamma.detach(), ctx.row_pad, mean, rstd,
                                              ctx.p_drop, ctx.seed, want_dx_colsum=True)
         if dx.data_ptr() == dres.data_ptr():
@@ -607,6 +634,7 @@ class AddLNFn(torch.autograd.Function):
             # whose last GEMM accumulates the input gradient into it, instead of returning it here
             # and letting autograd add the two (T, d) tensors in a separate pass.
             dx._sk_dres = (dx.data_ptr(), dres)
+            _pending_dres[dx.data_ptr()] = True
             dres = None
         return dx, dres, dg, db, None, None, None, None
 
@@ -632,6 +660,7 @@ class EmbedFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         (seq,) = ctx.saved_tensors
+        _check_residual_handoff()
         dW = torch.zeros(ctx.shape, dtype=torch.float32, device=dout.device)
         L.embed_bwd(seq, dout.contiguous(), dW, PAD)
         return None, None, dW, None, None

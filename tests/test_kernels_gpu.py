@@ -499,6 +499,34 @@ def test_adam_golden(L):
         assert torch.equal(b[0], p[0].to(torch.bfloat16)) and torch.equal(b[1], p[1].to(torch.bfloat16))
 
 
+def test_fused_adam_tables_survive_a_host_that_runs_ahead(L):
+    """Ten optimiser steps enqueued behind a long-running kernel, with no host synchronisation between them and a
+    freshly allocated gradient tensor per step (so every step uploads a different pointer table): each step
+    must read ITS table, not a later one's.  Checked against torch.optim.Adam on the CPU."""
+    from specialk_amd.optim import FusedAdam
+    g = torch.Generator().manual_seed(21)
+    w0 = [torch.randn(300, 40, generator=g), torch.randn(77, generator=g)]
+    grads = [[torch.randn(w.shape, generator=g) for w in w0] for _ in range(10)]
+    ref_p = [torch.nn.Parameter(w.clone()) for w in w0]
+    ref = torch.optim.Adam(ref_p, lr=1e-2, betas=(0.9, 0.98), eps=1e-9)
+    for gs in grads:
+        for p, gr in zip(ref_p, gs):
+            p.grad = gr.clone()
+        ref.step()
+    dev_p = [torch.nn.Parameter(w.clone().to(DEV)) for w in w0]
+    opt = FusedAdam(dev_p, lr=1e-2, betas=(0.9, 0.98), eps=1e-9)
+    dev_grads = [[gr.to(DEV) for gr in gs] for gs in grads]  # all alive at once: ten distinct addresses per parameter
+    torch.cuda.synchronize()
+    torch.cuda._sleep(int(2.0e8))  # ~0.1 s of GPU time: the host enqueues all ten steps meanwhile
+    for gs in dev_grads:
+        for p, gr in zip(dev_p, gs):
+            p.grad = gr
+        opt.step()
+    torch.cuda.synchronize()
+    for p, r in zip(dev_p, ref_p):
+        assert rel_err(p, r) <= 1e-5
+
+
 def test_cast_and_convert(L):
     a = [torch.randn(1000, device=DEV), torch.randn(3, 5, device=DEV)]
     b = [torch.empty(t.shape, dtype=torch.bfloat16, device=DEV) for t in a]
