@@ -238,6 +238,166 @@ __device__ __forceinline__ void write_tile(const GemmParams& p, const f32x4_t (*
   }
 }
 
+// Epilogue of a FULL interior 128 x 64 wave tile of the 256-tile kernels in the permuted layout (a lane owns
+// 16 consecutive columns of one row in each of the eight 16-row groups; 16-byte aligned C, bias and pattern).
+// write_tile above handles one row group at a time: load what the epilogue reads, wait, store, eight times in
+// a row, each time exposing a full memory round trip.  Here the bias is fetched once per tile and the old C
+// values (accumulate form) and sign-pattern words of a PAIR of row groups are requested together, so a tile
+// exposes one round trip (plain form) or four instead of eight or more.
+// Supported: alpha, bias, ReLU, sign pattern out / in, accumulate (bf16 output only).  The caller checks
+// full_epilogue_ok() and otherwise takes write_tile.
+//
+// Each batch of loads is one inline-assembly statement that ends in its own s_waitcnt vmcnt(0): the loads of a
+// batch are in flight together whatever the compiler would have made of the surrounding run-time branches (it
+// orders a load, its wait and the store of the previous row group strictly one after the other otherwise).
+__device__ __forceinline__ bool full_epilogue_ok(const GemmParams& p, bool out_is_bf16) {
+  return p.vec_c && !(p.epi & SK_EPI_RELU_MASK) && (out_is_bf16 || !(p.epi & SK_EPI_ACCUM));
+}
+
+__device__ float g_zero_bias[16];  // stands in for the bias of a lane's 16 columns when there is none
+
+__device__ __forceinline__ void load4x16_wait(const void* ptr, uint4& a, uint4& b, uint4& c, uint4& d) {
+  asm volatile(
+      "global_load_dwordx4 %0, %4, off\n\t"
+      "global_load_dwordx4 %1, %4, off offset:16\n\t"
+      "global_load_dwordx4 %2, %4, off offset:32\n\t"
+      "global_load_dwordx4 %3, %4, off offset:48\n\t"
+      "s_waitcnt vmcnt(0)"
+      : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d)
+      : "v"(ptr)
+      : "memory");
+}
+// two rows x 32 bytes
+__device__ __forceinline__ void load2x32_wait(const void* p0, const void* p1, uint4& a0, uint4& a1, uint4& b0, uint4& b1) {
+  asm volatile(
+      "global_load_dwordx4 %0, %4, off\n\t"
+      "global_load_dwordx4 %1, %4, off offset:16\n\t"
+      "global_load_dwordx4 %2, %5, off\n\t"
+      "global_load_dwordx4 %3, %5, off offset:16\n\t"
+      "s_waitcnt vmcnt(0)"
+      : "=&v"(a0), "=&v"(a1), "=&v"(b0), "=&v"(b1)
+      : "v"(p0), "v"(p1)
+      : "memory");
+}
+__device__ __forceinline__ void load2x8_wait(const void* p0, const void* p1, uint2& a, uint2& b) {
+  asm volatile(
+      "global_load_dwordx2 %0, %2, off\n\t"
+      "global_load_dwordx2 %1, %3, off\n\t"
+      "s_waitcnt vmcnt(0)"
+      : "=&v"(a), "=&v"(b)
+      : "v"(p0), "v"(p1)
+      : "memory");
+}
+// two rows x (32 bytes + an 8-byte word), one wait
+__device__ __forceinline__ void load2x32_2x8_wait(const void* p0, const void* p1, const void* w0, const void* w1, uint4& a0,
+                                                  uint4& a1, uint4& b0, uint4& b1, uint2& x, uint2& y) {
+  asm volatile(
+      "global_load_dwordx4 %0, %6, off\n\t"
+      "global_load_dwordx4 %1, %6, off offset:16\n\t"
+      "global_load_dwordx4 %2, %7, off\n\t"
+      "global_load_dwordx4 %3, %7, off offset:16\n\t"
+      "global_load_dwordx2 %4, %8, off\n\t"
+      "global_load_dwordx2 %5, %9, off\n\t"
+      "s_waitcnt vmcnt(0)"
+      : "=&v"(a0), "=&v"(a1), "=&v"(b0), "=&v"(b1), "=&v"(x), "=&v"(y)
+      : "v"(p0), "v"(p1), "v"(w0), "v"(w1)
+      : "memory");
+}
+
+template <typename TOut>
+__device__ __forceinline__ void write_wave_tile_full(const GemmParams& p, const f32x4_t (*acc)[4], int row0, int col0,
+                                                     int lane, char* scratch) {
+  const int g = lane >> 4, col = col0 + 16 * g;
+  const int epi = p.epi;
+  const float alpha = p.alpha;
+  const bool accum = sizeof(TOut) == 2 && (epi & SK_EPI_ACCUM), maskb = epi & SK_EPI_RELU_MASK_BITS;
+  float bias[16];
+  {
+    uint4 b[4];
+    load4x16_wait((epi & SK_EPI_BIAS) ? (const void*)(p.bias + col) : (const void*)g_zero_bias, b[0], b[1], b[2], b[3]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      bias[4 * i] = __uint_as_float(b[i].x); bias[4 * i + 1] = __uint_as_float(b[i].y);
+      bias[4 * i + 2] = __uint_as_float(b[i].z); bias[4 * i + 3] = __uint_as_float(b[i].w);
+    }
+  }
+  const int q = (col >> 4) & 3;  // which 16-column quarter of the 64-column pattern word this lane holds
+#pragma unroll
+  for (int pair = 0; pair < 4; ++pair) {
+    uint4 oldc[2][2];
+    uint2 words[2];
+    const int64_t r0 = row0 + (2 * pair) * 16 + (lane & 15), r1 = r0 + 16;
+    const void* c0 = (const bf16_t*)p.C + r0 * p.ldc + col;
+    const void* c1 = (const bf16_t*)p.C + r1 * p.ldc + col;
+    const void* w0 = (const uint64_t*)p.aux + ((r0 * p.N + col) >> 6);
+    const void* w1 = (const uint64_t*)p.aux + ((r1 * p.N + col) >> 6);
+    if (accum && maskb) load2x32_2x8_wait(c0, c1, w0, w1, oldc[0][0], oldc[0][1], oldc[1][0], oldc[1][1], words[0], words[1]);
+    else if (accum) load2x32_wait(c0, c1, oldc[0][0], oldc[0][1], oldc[1][0], oldc[1][1]);
+    else if (maskb) load2x8_wait(w0, w1, words[0], words[1]);
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const int mi = 2 * pair + m;
+      const int64_t row = m ? r1 : r0;
+      float v[16];
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[ni * 4 + r] = acc[mi][ni][r] * alpha + bias[ni * 4 + r];
+      if (epi & SK_EPI_RELU) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] = fmaxf(v[j], 0.f);
+      }
+      if (epi & SK_EPI_RELU_BITS_OUT) {
+        uint32_t bits = 0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) bits |= (v[j] > 0.f ? 1u : 0u) << j;
+        const uint32_t other = __shfl_xor(bits, 16, 64);
+        const uint32_t pr = (q & 1) ? (other | (bits << 16)) : (bits | (other << 16));
+        const uint32_t pr2 = __shfl_xor(pr, 32, 64);
+        if (q == 0) *((uint64_t*)p.aux + ((row * p.N + col) >> 6)) = (uint64_t)pr | ((uint64_t)pr2 << 32);
+      }
+      if (maskb) {
+        const uint64_t word = (uint64_t)words[m].x | ((uint64_t)words[m].y << 32);
+        const uint32_t bits = (uint32_t)(word >> (16 * q));
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] = (bits >> j) & 1u ? v[j] : 0.f;
+      }
+      if (accum) {
+        const bf16_t* e0 = (const bf16_t*)&oldc[m][0];
+        const bf16_t* e1 = (const bf16_t*)&oldc[m][1];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { v[j] += bf16_to_f32(e0[j]); v[8 + j] += bf16_to_f32(e1[j]); }
+      }
+      if constexpr (sizeof(TOut) == 2) {
+        // Through the wave's 2 KiB of LDS scratch so that eight consecutive lanes store one whole 128-byte line:
+        // stored straight from the accumulator layout, consecutive lanes are different ROWS, every 16-byte piece
+        // is a memory request of its own (64 per instruction instead of 8), and the loads of the next tile queue
+        // behind them (measured on 25.6 k x 2048 x 512: 7 -> 5 thousand cycles per tile epilogue, 84 -> 75 us per launch).
+        uint4 h0, h1;
+        {
+          bf16_t* e0 = (bf16_t*)&h0;
+          bf16_t* e1 = (bf16_t*)&h1;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { e0[j] = f32_to_bf16(v[j]); e1[j] = f32_to_bf16(v[8 + j]); }
+        }
+        const int r15 = lane & 15;
+        *(uint4*)(scratch + r15 * 128 + (((2 * g) ^ (r15 & 7)) << 4)) = h0;
+        *(uint4*)(scratch + r15 * 128 + (((2 * g + 1) ^ (r15 & 7)) << 4)) = h1;
+        const int c = lane & 7;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int rho = (lane >> 3) + 8 * j;
+          const uint4 o = *(const uint4*)(scratch + rho * 128 + ((c ^ (rho & 7)) << 4));
+          bf16_t* dst = (bf16_t*)p.C + (int64_t)(row0 + mi * 16 + rho) * p.ldc + col0 + 8 * c;
+          *(uint4*)dst = o;
+        }
+      } else {
+        store_cols<TOut, 16>((TOut*)p.C + row * p.ldc + col, v);
+      }
+    }
+  }
+}
+
 // ============================================================================ bf16
 namespace b16 {
 constexpr int BK = 64;
@@ -587,6 +747,8 @@ constexpr int XM = 256, XN = 256, BK = 32, STAGES = 4;
 constexpr int OPER_BYTES = 256 * BK * 2;         // 16384
 constexpr int STAGE_BYTES = 2 * OPER_BYTES;      // A + B
 constexpr int SMEM_BYTES = STAGES * STAGE_BYTES;  // 128 KiB
+constexpr int EPI_SCRATCH_BYTES = 8 * 2048;       // per wave 16 rows x 128 bytes behind the ring: see write_wave_tile_full
+constexpr int LDS_BYTES = SMEM_BYTES + EPI_SCRATCH_BYTES;
 
 using b16::key_t;
 using b16g::g_zero_page;
@@ -750,6 +912,12 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, int tile_m, int t
   }
   if (wave < 4) __builtin_amdgcn_s_barrier();  // balances the upper half's extra barrier
 
+  if constexpr (!B_T) {
+    if (slab < 0 && m0 + XM <= p.M && n0 + XN <= p.N && full_epilogue_ok(p, sizeof(TOut) == 2)) {
+      write_wave_tile_full<TOut>(p, acc, m0 + wrow, n0 + wcol, lane, smem + SMEM_BYTES + wave * 2048);
+      return;
+    }
+  }
   write_tile<TOut, bf16_t, !B_T>(p, acc, m0 + wrow, n0 + wcol, lane, slab);
   write_tile<TOut, bf16_t, !B_T>(p, acc + 4, m0 + wrow + 64, n0 + wcol, lane, slab);
 }
@@ -1188,6 +1356,11 @@ static int gemm_one(int layout, const void* A, const void* B, void* C, const voi
     const int64_t rounds = (t256 + ncu - 1) / ncu;
     const double fill = (double)t256 / (double)(rounds * ncu);
     use_big = t256 >= 8 * ncu || (K >= 1024 && fill >= 0.7) || (rounds == 1 && fill >= 0.7);
+    // whole 256-column tiles of a tall product: the 256-tile kernel's full-tile epilogue stores whole 128-byte
+    // lines (through LDS) where the 128-tile kernel stores 16-byte pieces; inside the training step that outweighs
+    // the 128-tile kernel's better round fill (17.93 -> 17.73 ms per step, interleaved in one process)
+    // (not below three quarters of a round of tiles: those products would be K-split, with another summation order)
+    if (layout == SK_GEMM_NT && M >= 8192 && N % 256 == 0 && out_dtype == SK_BF16 && 4 * t256 >= 3 * ncu) use_big = true;
     if (use_big && nn_long) use_staged = false;
   }
   // Weight gradients (TN, long K, split-K): the 256-tile kernel when the output has enough 256-tiles
@@ -1237,9 +1410,9 @@ static int gemm_one(int layout, const void* A, const void* B, void* C, const voi
   if (use_big) {
 #define LAUNCH_BIG(AT, BT, TO)                                                                          \
   do {                                                                                                  \
-    int rc = sk_allow_big_lds(b16x::gemm_kernel<AT, BT, TO>, b16x::SMEM_BYTES);                         \
+    int rc = sk_allow_big_lds(b16x::gemm_kernel<AT, BT, TO>, b16x::LDS_BYTES);                         \
     if (rc) return rc;                                                                                  \
-    hipLaunchKernelGGL((b16x::gemm_kernel<AT, BT, TO>), grid, dim3(512), b16x::SMEM_BYTES, stream, p);  \
+    hipLaunchKernelGGL((b16x::gemm_kernel<AT, BT, TO>), grid, dim3(512), b16x::LDS_BYTES, stream, p);  \
   } while (0)
     if (out_dtype == SK_BF16) {
       if (layout == SK_GEMM_NT) LAUNCH_BIG(false, false, bf16_t);
@@ -1394,7 +1567,7 @@ extern "C" int skhip_gemm_grouped_tn(const int64_t* problems, int n, void* works
   }
 
   // ---- launches, at most MAX_GROUP descriptors each
-  int rc = sk_allow_big_lds(b16x::gemm_grouped_tn_kernel, b16x::SMEM_BYTES);
+  int rc = sk_allow_big_lds(b16x::gemm_grouped_tn_kernel, b16x::LDS_BYTES);
   if (rc) return rc;
   for (size_t c0 = 0; c0 < descs.size(); c0 += b16x::MAX_GROUP) {
     GroupArgs g;
@@ -1411,7 +1584,7 @@ extern "C" int skhip_gemm_grouped_tn(const int64_t* problems, int n, void* works
         max_red = (int)std::max<int64_t>(max_red, need < 1 ? 1 : need > 512 ? 512 : need);
       }
     }
-    hipLaunchKernelGGL(b16x::gemm_grouped_tn_kernel, dim3(blocks), dim3(512), b16x::SMEM_BYTES, stream, g);
+    hipLaunchKernelGGL(b16x::gemm_grouped_tn_kernel, dim3(blocks), dim3(512), b16x::LDS_BYTES, stream, g);
     SK_CHECK_LAUNCH("skhip_gemm_grouped_tn");
     if (max_red > 0) {
       hipLaunchKernelGGL(b16x::grouped_reduce_kernel, dim3(max_red, g.n), dim3(256), 0, stream, g);
