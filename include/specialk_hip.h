@@ -74,10 +74,13 @@ int skhip_gemm(int layout, const void* A, const void* B, void* C, const void* bi
  * the autograd backward of every nn.Linear / Conv1d(k=1) weight of the layers (SubLayers.py:46-48,62,
  * 73-74), which the reference's autograd engine runs as one small GEMM per weight.  A_i (K_i x M_i,
  * row stride lda_i) and B_i (K_i x N_i, ldb_i) are bf16 with rows contiguous, C_i (M_i x N_i, ldc_i) is
- * fp32.  problems: HOST array of n x 10 int64 {A, B, C, M, N, K, lda, ldb, ldc, accumulate}; operand
- * addresses, M, N, lda, ldb must be multiples of 16 bytes / 8 elements.  workspace: fp32 scratch for the
- * K-split slabs of the tiles that do not fill a whole round of the chip (NULL: no split).
- * Deterministic (fixed summation order).                                                     */
+ * fp32.  problems: HOST array of n x 12 int64 {A, B, C, M, N, K, lda, ldb, ldc, accumulate, colsum,
+ * colsum_accumulate}; operand addresses, M, N, lda, ldb must be multiples of 16 bytes / 8 elements.  colsum
+ * (optional, 0 = none) is an fp32 [M_i] vector that receives (or, with colsum_accumulate, is added) the column
+ * sums of A_i: with A_i = dy these are the bias gradient of the same layer (the autograd backward of the
+ * `+ bias` in nn.Linear), computed on the matrix pipe beside the weight gradient instead of in a pass of its
+ * own over dy.  workspace: fp32 scratch for the K-split slabs of the tiles that do not fill a whole round of
+ * the chip (NULL: no split).  Deterministic (fixed summation order).                                  */
 int skhip_gemm_grouped_tn(const int64_t* problems, int n, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* Column sums: out[n] (+)= sum_m X[m][n]  (bias gradients, the autograd backward of the

@@ -145,16 +145,21 @@ def gemm(layout, A, B, M, N, K, lda, ldb, out=None, ldc=None, bias=None, aux=Non
 
 
 def gemm_grouped_tn(problems):
-    """problems: list of (A, B, C, M, N, K, lda, ldb, ldc, accumulate) with A (K, M) and B (K, N) bf16 views
-    (rows contiguous), C (M, N) fp32: C (+)= A^T B for all of them in one pass over the chip."""
+    """problems: list of (A, B, C, M, N, K, lda, ldb, ldc, accumulate[, colsum, colsum_accumulate]) with A (K, M) and
+    B (K, N) bf16 views (rows contiguous), C (M, N) fp32: C (+)= A^T B for all of them in one pass over the chip;
+    colsum (optional fp32 (M,)) (+)= column sums of A."""
     lib = load()
     n = len(problems)
     if n == 0:
         return
-    table = (c_i64 * (10 * n))()
-    for i, (A, B, C, M, N, K, lda, ldb, ldc, acc) in enumerate(problems):
+    table = (c_i64 * (12 * n))()
+    for i, pr in enumerate(problems):
+        A, B, C, M, N, K, lda, ldb, ldc, acc = pr[:10]
+        cs, cs_acc = (pr[10], pr[11]) if len(pr) > 10 else (None, False)
         assert A.dtype == torch.bfloat16 and B.dtype == torch.bfloat16 and C.dtype == torch.float32
-        table[10 * i:10 * i + 10] = [A.data_ptr(), B.data_ptr(), C.data_ptr(), M, N, K, lda, ldb, ldc, int(bool(acc))]
+        assert cs is None or (cs.dtype == torch.float32 and cs.is_contiguous() and cs.numel() == M)
+        table[12 * i:12 * i + 12] = [A.data_ptr(), B.data_ptr(), C.data_ptr(), M, N, K, lda, ldb, ldc, int(bool(acc)),
+                                     cs.data_ptr() if cs is not None else 0, int(bool(cs_acc))]
     ws = workspace(192 << 20)  # up to two rounds of 256 CUs x 256 KB tile slabs, with room to spare
     _check(lib.skhip_gemm_grouped_tn(table, n, _ptr(ws), ws.numel(), _stream()), "skhip_gemm_grouped_tn")
 

@@ -60,6 +60,11 @@ struct GemmParams {
   int vec_c;  // C (and aux) allow 16-byte vector access
   float alpha;
   int group;  // tile rows per rasterisation group (see tile_of)
+  // TN products of the grouped launch only: also out[m] (+)= sum_k A[k][m], the column sums of the first operand
+  // (the bias gradient that belongs to a weight gradient dy^T x); null otherwise
+  float* colsum;
+  float* colsum_ws;  // [splits][M] partial sums when the product is K-split
+  int colsum_acc;
 };
 
 constexpr int BM = 128, BN = 128;
@@ -879,6 +884,17 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, int tile_m, int t
     }
   }
 
+  // Column sums of the A operand (TN products: A is [k][m], so these are sums over the contraction index) ride on
+  // the matrix pipe: a product of an all-ones fragment with the A fragment is a 16 x 16 tile whose every row holds
+  // the sums of the fragment's 16 columns.  Only the blocks of tile column 0 do it, and each of the four waves
+  // that share the block's rows takes two of the eight row groups: two more MFMAs per wave and K-step (+6 %).
+  bool do_colsum = false;
+  if constexpr (A_T && B_T) do_colsum = p.colsum != nullptr && tile_n == 0;
+  f32x4_t csum[2] = {f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}};
+  const s16x8_t ones_bits = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};  // bf16 1.0
+  const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, ones_bits);
+  const int cs_mi = 2 * (wave & 3);
+
   int cs = 0, is = 3;  // stage being computed / stage being filled
   for (int kt = 0; kt < nk; ++kt) {
     // ---- R: fragments of tile kt, loads of tile kt+3
@@ -905,12 +921,33 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, int tile_m, int t
 #pragma unroll
       for (int ni = 0; ni < 4; ++ni)
         acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[ni], fa[mi], acc[mi][ni], 0, 0, 0);
+    if constexpr (A_T && B_T) {
+      if (do_colsum) {
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi)  // static register indices: the wave's pair is picked by a uniform compare
+          if (mi >> 1 == (wave & 3))
+            csum[mi & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fa[mi], csum[mi & 1], 0, 0, 0);
+      }
+    }
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
     cs = cs == STAGES - 1 ? 0 : cs + 1;
     is = is == STAGES - 1 ? 0 : is + 1;
   }
   if (wave < 4) __builtin_amdgcn_s_barrier();  // balances the upper half's extra barrier
+
+  if constexpr (A_T && B_T) {
+    if (do_colsum && lane < 16) {  // lanes 0..15, register 0: the sums of columns 16 * mi + lane
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int m = m0 + wrow + 16 * (cs_mi + j) + lane;
+        if (m < p.M) {
+          if (slab >= 0) p.colsum_ws[(int64_t)slab * p.M + m] = csum[j][0];
+          else p.colsum[m] = p.colsum_acc ? p.colsum[m] + csum[j][0] : csum[j][0];
+        }
+      }
+    }
+  }
 
   if constexpr (!B_T) {
     if (slab < 0 && m0 + XM <= p.M && n0 + XN <= p.N && full_epilogue_ok(p, sizeof(TOut) == 2)) {
@@ -939,14 +976,15 @@ struct GroupDesc {
   const void* A;
   const void* B;
   float* C;
-  float* ws;         // slabs [splits][M][N] when splits > 1
+  float* ws;         // slabs [splits][M][N] when splits > 1, followed by [splits][M] column-sum partials
+  float* colsum;     // optional: out[m] (+)= sum_k A[k][m]
   int M, N, K;
   int lda, ldb, ldc;
   int first_block;   // blocks of the problems before this one
   int splits, kps;   // K splits and K per split
-  int flags;         // bit 0: accumulate into C, bit 1: C allows 16-byte access
+  int flags;         // bit 0: accumulate into C, bit 1: C allows 16-byte access, bit 2: accumulate into colsum
 };
-constexpr int MAX_GROUP = 48;
+constexpr int MAX_GROUP = 44;
 struct GroupArgs {
   int n, pad;
   GroupDesc d[MAX_GROUP];
@@ -965,6 +1003,9 @@ __device__ __forceinline__ GemmParams params_of(const GroupDesc& d) {
   p.vec_c = (d.flags >> 1) & 1;
   p.alpha = 1.f;
   p.group = 1;
+  p.colsum = d.colsum;
+  p.colsum_ws = d.ws ? d.ws + (int64_t)d.splits * d.M * d.N : nullptr;
+  p.colsum_acc = (d.flags >> 2) & 1;
   return p;
 }
 
@@ -988,6 +1029,14 @@ __global__ __launch_bounds__(256) void grouped_reduce_kernel(GroupArgs g) {
   if (d.splits <= 1) return;
   const int64_t total = (int64_t)d.M * d.N;
   const bool acc = d.flags & 1;
+  if (d.colsum && blockIdx.x == 0) {  // the column-sum partials, in split order
+    const float* part = d.ws + (int64_t)d.splits * total;
+    for (int m = threadIdx.x; m < d.M; m += blockDim.x) {
+      float sum = 0.f;
+      for (int z = 0; z < d.splits; ++z) sum += part[(int64_t)z * d.M + m];
+      d.colsum[m] = (d.flags & 4) ? d.colsum[m] + sum : sum;
+    }
+  }
   if ((d.N & 3) == 0 && (d.flags & 2)) {
     for (int64_t i = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) * 4; i < total; i += (int64_t)gridDim.x * blockDim.x * 4) {
       float4 s = *(const float4*)(d.ws + i);
@@ -1303,6 +1352,8 @@ static int gemm_one(int layout, const void* A, const void* B, void* C, const voi
   GemmParams p;
   p.A = A; p.B = B; p.C = C; p.bias = (const float*)bias; p.aux = aux;
   p.ws = nullptr;
+  p.colsum = p.colsum_ws = nullptr;
+  p.colsum_acc = 0;
   p.lda = lda; p.ldb = ldb; p.ldc = ldc;
   p.M = (int)M; p.N = (int)N; p.K = (int)K;
   p.tiles_m = (int)((M + BM - 1) / BM);
@@ -1457,10 +1508,12 @@ static int gemm_one(int layout, const void* A, const void* B, void* C, const voi
 // Grouped weight gradients: n independent products C_i (M_i x N_i fp32, row stride ldc_i) (+)= A_i^T B_i
 // with row-contiguous bf16 operands A_i (K_i x M_i, row stride lda_i), B_i (K_i x N_i, ldb_i), all in as
 // few launches as the 4 KB argument limit allows (48 sub-problems each).  `problems` is a HOST array
-// of n x 10 int64: {A, B, C, M, N, K, lda, ldb, ldc, accumulate}.  Scheduling: the 256-tiles of all
+// of n x 12 int64: {A, B, C, M, N, K, lda, ldb, ldc, accumulate, colsum, colsum_accumulate} (colsum: optional
+// fp32 [M] that receives the column sums of A_i, i.e. the bias gradient that goes with the weight gradient).  Scheduling: the 256-tiles of all
 // problems are laid out in order; those that fill whole rounds of the chip's CUs run unsplit, the
 // remainder (fewer tiles than CUs) is cut off at a tile-row boundary and K-split so that it, too,
 // occupies every CU once, with slabs in `workspace` and a reduction in split order (deterministic).
+constexpr int kProblemFields = 12;
 extern "C" int skhip_gemm_grouped_tn(const int64_t* problems, int n, void* workspace, int64_t workspace_bytes,
                                      void* stream_) {
   using b16x::GroupArgs;
@@ -1471,7 +1524,7 @@ extern "C" int skhip_gemm_grouped_tn(const int64_t* problems, int n, void* works
   const int ncu = sk_num_cus();
   int64_t total_tiles = 0;
   for (int i = 0; i < n; ++i) {
-    const int64_t* q = problems + 10 * i;
+    const int64_t* q = problems + kProblemFields * i;
     const int64_t M = q[3], N = q[4], K = q[5], lda = q[6], ldb = q[7], ldc = q[8];
     SK_CHECK_ARG(q[0] && q[1] && q[2], "skhip_gemm_grouped_tn: null operand in problem %d", i);
     SK_CHECK_ARG(M > 0 && N > 0 && K > 0 && M < (1ll << 31) && N < (1ll << 31) && K < (1ll << 31) &&
@@ -1502,14 +1555,14 @@ extern "C" int skhip_gemm_grouped_tn(const int64_t* problems, int n, void* works
   };
   if (total_tiles < ncu) {  // not even one round: split everything alike
     const int sp = best_splits(total_tiles);
-    for (int i = 0; i < n; ++i) subs.push_back({i, 0, problems[10 * i + 3], sp});
+    for (int i = 0; i < n; ++i) subs.push_back({i, 0, problems[kProblemFields * i + 3], sp});
   } else {
     int64_t used = 0;
     bool in_tail = false;
     int64_t tail_tiles = 0;
     std::vector<Sub> tail;
     for (int i = 0; i < n; ++i) {
-      const int64_t M = problems[10 * i + 3], tn = (problems[10 * i + 4] + 255) / 256, tm = (M + 255) / 256;
+      const int64_t M = problems[kProblemFields * i + 3], tn = (problems[kProblemFields * i + 4] + 255) / 256, tm = (M + 255) / 256;
       if (in_tail) { tail.push_back({i, 0, M, 1}); tail_tiles += tm * tn; continue; }
       if (used + tm * tn <= full_tiles) { subs.push_back({i, 0, M, 1}); used += tm * tn; continue; }
       const int64_t rows_here = (full_tiles - used) / tn;  // whole tile rows that still fit the full rounds
@@ -1532,8 +1585,8 @@ extern "C" int skhip_gemm_grouped_tn(const int64_t* problems, int n, void* works
       int64_t b = 0;
       for (const Sub& sb : subs)
         if (sb.splits > 1) {
-          const int64_t K = problems[10 * sb.prob + 5];
-          b += (int64_t)std::min(spl, max_splits_of(K)) * (sb.r1 - sb.r0) * problems[10 * sb.prob + 4] * 4;
+          const int64_t K = problems[kProblemFields * sb.prob + 5];
+          b += (int64_t)std::min(spl, max_splits_of(K)) * (sb.r1 - sb.r0) * (problems[kProblemFields * sb.prob + 4] + 1) * 4;
         }
       return b;
     };
@@ -1545,7 +1598,7 @@ extern "C" int skhip_gemm_grouped_tn(const int64_t* problems, int n, void* works
   std::vector<GroupDesc> descs;
   int64_t ws_used = 0;
   for (const Sub& sb : subs) {
-    const int64_t* q = problems + 10 * sb.prob;
+    const int64_t* q = problems + kProblemFields * sb.prob;
     GroupDesc d;
     d.M = (int)(sb.r1 - sb.r0); d.N = (int)q[4]; d.K = (int)q[5];
     d.lda = (int)q[6]; d.ldb = (int)q[7]; d.ldc = (int)q[8];
@@ -1553,7 +1606,7 @@ extern "C" int skhip_gemm_grouped_tn(const int64_t* problems, int n, void* works
     d.B = (const void*)q[1];
     d.C = (float*)q[2] + sb.r0 * d.ldc;
     int splits = sb.splits < max_splits_of(d.K) ? sb.splits : max_splits_of(d.K);
-    const int64_t slab = (int64_t)d.M * d.N * 4;
+    const int64_t slab = (int64_t)d.M * (d.N + 1) * 4;  // C partials and one row of column-sum partials
     if (splits > 1 && ws_used + splits * slab > workspace_bytes) splits = 1;  // cannot happen after the uniform cut above
     int kps = (d.K + splits - 1) / splits;
     kps = (kps + b16x::BK - 1) / b16x::BK * b16x::BK;
@@ -1561,7 +1614,8 @@ extern "C" int skhip_gemm_grouped_tn(const int64_t* problems, int n, void* works
     d.splits = splits; d.kps = kps;
     d.ws = nullptr;
     if (splits > 1) { d.ws = (float*)((char*)workspace + ws_used); ws_used += splits * slab; }
-    d.flags = (q[9] ? 1 : 0) | ((((uintptr_t)d.C % 16 == 0) && d.ldc % 4 == 0) ? 2 : 0);
+    d.colsum = q[10] ? (float*)q[10] + sb.r0 : nullptr;
+    d.flags = (q[9] ? 1 : 0) | ((((uintptr_t)d.C % 16 == 0) && d.ldc % 4 == 0) ? 2 : 0) | (q[11] ? 4 : 0);
     d.first_block = 0;
     descs.push_back(d);
   }

@@ -180,43 +180,6 @@ def _bias_grad(dy, T, N):
     return L.colsum(dy, T, N, N)
 
 
-_side_streams = {}
-
-
-def _colsum_overlapped(dy, T, N, ld, biases):
-    """Column sums of dy (T, N; row stride ld) = the gradients of `biases` (the parameters the result is
-    split over).  Inside batched_weight_grads() on a single GPU the HBM-bound reduction runs on a second
-    stream beside the latency-bound input-gradient GEMMs of the main stream; the context joins the streams
-    when it exits, before anything reads a gradient.  Not taken when a bias already holds a gradient (autograd
-    would then add to it on the main stream straight away), nor when a reducer consumes gradients during
-    backward (on_ready) unless it declares `joins_side_stream` — that it calls join_side_stream() before it
-    reads gradients that autograd handed to it."""
-    b = _wgrad_batch
-    reducer = getattr(b.on_ready, "__self__", None) if b is not None and b.on_ready is not None else None
-    if b is None or not b.overlap or any(p.grad is not None for p in biases) or \
-            (b.on_ready is not None and not getattr(reducer, "joins_side_stream", False)):
-        return L.colsum(dy, T, N, ld)
-    main = torch.cuda.current_stream(dy.device)
-    side = _side_streams.get(dy.device)
-    if side is None:
-        side = _side_streams[dy.device] = torch.cuda.Stream(dy.device)
-    out = torch.empty(N, dtype=torch.float32, device=dy.device)
-    side.wait_stream(main)
-    with torch.cuda.stream(side):
-        L.colsum(dy, T, N, ld, out=out)
-    dy.record_stream(side)
-    out.record_stream(side)
-    b.side = side
-    return out
-
-
-def join_side_stream():
-    """Make the current stream wait for the bias-gradient reductions issued so far on the second stream."""
-    b = _wgrad_batch
-    if b is not None and b.side is not None:
-        torch.cuda.current_stream().wait_stream(b.side)
-
-
 _pending_dres = {}  # data_ptr of a gradient whose residual part AddLNFn.backward handed on -> not yet picked up
 
 
@@ -295,8 +258,6 @@ class _WeightGradBatch:
     def __init__(self, on_ready, flush_tiles):
         self.on_ready, self.flush_tiles = on_ready, flush_tiles
         self.items, self.tiles, self.seen = [], 0, set()
-        self.side = None  # second stream, once a bias-gradient reduction has been put on it
-        self.overlap = os.environ.get("SK_COLSUM_OVERLAP", "1") != "0"
 
 
 _wgrad_batch = None
@@ -316,7 +277,10 @@ def batched_weight_grads(on_ready=None, flush_tiles=256):
     hundred equal work items.  (Thresholds of 512 or 1024 tiles measured 3 % slower end to end than 256:
     the queued operands leave the caches before they are used.)  on_ready(params) is called after each grouped launch with the
     parameters whose gradients it wrote (a data-parallel reducer's cue; autograd hooks do not fire
-    for these parameters).  Bias, LayerNorm and embedding gradients still flow through autograd."""
+    for these parameters).  The bias gradient that goes with a queued weight gradient (the column sums of the same
+    dy) is computed by the same launch on the matrix pipe and written to `b.grad` alike — straight into the
+    reducer's bucket when on_ready belongs to an object with a bucket_view(p) method.  Output-projection bias,
+    LayerNorm and embedding gradients still flow through autograd."""
     global _wgrad_batch
     if _wgrad_batch is not None:
         raise RuntimeError("batched_weight_grads() does not nest")
@@ -324,10 +288,23 @@ def batched_weight_grads(on_ready=None, flush_tiles=256):
     try:
         yield
         _flush_weight_grads()
-        if _wgrad_batch.side is not None:  # bias-gradient reductions on the second stream: join
-            torch.cuda.current_stream().wait_stream(_wgrad_batch.side)
     finally:
         _wgrad_batch = None
+
+
+def _grad_target(p, fixups, reducer=None):
+    """(tensor the launch writes, accumulate?) for the gradient of p: p.grad itself when it can be written in
+    place, a fresh tensor that becomes p.grad when there is none, else a temporary that is added afterwards."""
+    g = p.grad
+    if g is None:
+        view = reducer.bucket_view(p) if reducer is not None and hasattr(reducer, "bucket_view") else None
+        g = p.grad = view if view is not None else torch.empty(p.shape, dtype=torch.float32, device=p.device)
+        return g, False
+    if g.dtype == torch.float32 and g.is_contiguous():
+        return g, True
+    out = torch.empty(p.shape, dtype=torch.float32, device=p.device)
+    fixups.append((g, out))
+    return out, False
 
 
 def _flush_weight_grads():
@@ -336,19 +313,15 @@ def _flush_weight_grads():
         return
     items, b.items, b.tiles, b.seen = b.items, [], 0, set()
     problems, fixups, params = [], [], []
+    reducer = getattr(b.on_ready, "__self__", None) if b.on_ready is not None else None
     with torch.no_grad():
-        for dy, x, W, n, d_in, T in items:
-            g = W.grad
-            if g is None:
-                g = W.grad = torch.empty(W.shape, dtype=torch.float32, device=W.device)
-                acc, out = False, g
-            elif g.dtype == torch.float32 and g.is_contiguous():
-                acc, out = True, g
-            else:
-                acc, out = False, torch.empty(W.shape, dtype=torch.float32, device=W.device)
-                fixups.append((g, out))
-            problems.append((dy, x, out, n, d_in, T, dy.stride(0), x.stride(0), d_in, acc))
+        for dy, x, W, n, d_in, T, bias in items:
+            out, acc = _grad_target(W, fixups)
+            cs, cs_acc = (None, False) if bias is None else _grad_target(bias, fixups, reducer)
+            problems.append((dy, x, out, n, d_in, T, dy.stride(0), x.stride(0), d_in, acc, cs, cs_acc))
             params.append(W)
+            if bias is not None:
+                params.append(bias)
         L.gemm_grouped_tn(problems)
         for g, out in fixups:
             g.add_(out)
@@ -356,25 +329,33 @@ def _flush_weight_grads():
         b.on_ready(params)
 
 
-def _weight_grad(dy, x, W, T, needed=True):
+def _batchable(dy, x):
+    n, d_in = dy.shape[1], x.shape[1]
+    return not (_wgrad_batch is None or dy.dtype != torch.bfloat16 or dy.stride(0) % 8 or x.stride(0) % 8 or n % 8 or d_in % 8
+                or dy.data_ptr() % 16 or x.data_ptr() % 16)
+
+
+def _weight_grad(dy, x, W, T, needed=True, bias=None):
     """dW (n, d_in) = dy (T, n; any row stride)^T x (T, d_in) for the weight W of shape (n, d_in[, 1]):
     returned for autograd, or — inside batched_weight_grads(), bf16 only — queued for the next grouped
-    launch, in which case None is returned and W.grad is written by that launch."""
-    if not needed:
-        return None
+    launch, in which case None is returned and W.grad is written by that launch.
+    bias: the layer's bias when its gradient (the column sums of dy) is wanted as well.  Returns (dW, db);
+    queued: (None, None), and the launch writes bias.grad too."""
     n, d_in = dy.shape[1], x.shape[1]
     b = _wgrad_batch
-    if b is None or dy.dtype != torch.bfloat16 or dy.stride(0) % 8 or x.stride(0) % 8 or n % 8 or d_in % 8 \
-            or dy.data_ptr() % 16 or x.data_ptr() % 16:
-        return L.gemm(L.GEMM_TN, dy, x, n, d_in, T, dy.stride(0), x.stride(0), out_dtype=torch.float32).view(W.shape)
+    if not needed or not _batchable(dy, x):
+        dW = None
+        if needed:
+            dW = L.gemm(L.GEMM_TN, dy, x, n, d_in, T, dy.stride(0), x.stride(0), out_dtype=torch.float32).view(W.shape)
+        return dW, (None if bias is None else L.colsum(dy, T, n, dy.stride(0)))
     if W.data_ptr() in b.seen:  # two products into one gradient must not share a launch
         _flush_weight_grads()
     b.seen.add(W.data_ptr())
-    b.items.append((dy, x, W, n, d_in, T))
+    b.items.append((dy, x, W, n, d_in, T, bias))
     b.tiles += ((n + 255) // 256) * ((d_in + 255) // 256)
     if b.tiles >= b.flush_tiles:
         _flush_weight_grads()
-    return None
+    return None, None
 
 
 def _unalias(dres, dy):
@@ -454,11 +435,10 @@ class FFNFn(torch.autograd.Function):
             dh = _input_grad(dy, d, (W2,), T, F, x.dtype, aux=ctx.signs, epilogue=L.EPI_RELU_MASK_BITS)
         else:
             dh = _input_grad(dy, d, (W2,), T, F, x.dtype, aux=h, epilogue=L.EPI_RELU_MASK)
-        dW2 = _weight_grad(dy, h, W2, T, ctx.needs_input_grad[3])
+        dW2, _ = _weight_grad(dy, h, W2, T, ctx.needs_input_grad[3])
         db2 = _bias_grad(dy, T, d)
         dx = _input_grad(dh, F, (W1,), T, d, x.dtype, add_to=dres)  # accumulates into dres in place
-        dW1 = _weight_grad(dh, x, W1, T, ctx.needs_input_grad[1])
-        db1 = _colsum_overlapped(dh, T, F, F, (b1,))
+        dW1, db1 = _weight_grad(dh, x, W1, T, ctx.needs_input_grad[1], bias=b1 if ctx.needs_input_grad[2] else None)
         return dx, dW1, db1, dW2, db2
 
 
@@ -525,7 +505,7 @@ class MHAFn(torch.autograd.Function):
         need = ctx.needs_input_grad
         # output projection
         dO = _input_grad(dout, d, (Wo,), Tq, nv, dt)
-        dWo = _weight_grad(dout, O, Wo, Tq, need[8])
+        dWo, _ = _weight_grad(dout, O, Wo, Tq, need[8])
         dbo = _bias_grad(dout, Tq, d)
         # attention core
         if cfg["self_attn"]:
@@ -541,31 +521,32 @@ class MHAFn(torch.autograd.Function):
         L.attn_bwd(Q, K, V, O, dO, lse, dQ, dK, dV, delta, B, H, Lq, Lk, dk, dv, ldq, ldk, ldv, nv, lddq, lddk, lddv,
                    cfg["scale"], key_pad=cfg["key_pad"], dense_mask=cfg["dense_mask"], causal=cfg["causal"],
                    p_drop=cfg["p_attn"], seed=ctx.seed, q_off=cfg.get("q_off"), k_off=cfg.get("k_off"))
-        # projections: weight gradients, bias gradients (column sums) and input gradients, each over the
-        # widest buffer that shares an input ([dq|dk|dv] for self-attention, [dk|dv] otherwise)
-        batched = _wgrad_batch is not None and dt == torch.bfloat16
+        # projections: weight gradients, bias gradients (column sums) and input gradients.  Queued for a grouped
+        # launch (bf16 inside batched_weight_grads()): one problem per parameter, each written straight into its
+        # .grad together with its bias gradient.  Otherwise one product and one column sum over the widest buffer
+        # that shares an input ([dq|dk|dv] for self-attention, [dk|dv] otherwise).
+        kv_src = q_in if cfg["self_attn"] else kv_in
+        batched = dt == torch.bfloat16 and _batchable(dQ, q_in) and _batchable(dK, kv_src) and _batchable(dV, kv_src)
+        if batched:
+            dWq, dbq = _weight_grad(dQ, q_in, Wq, Tq, need[2], bias=bq if need[3] else None)
+            dWk, dbk = _weight_grad(dK, kv_src, Wk, Tk, need[4], bias=bk if need[5] else None)
+            dWv, dbv = _weight_grad(dV, kv_src, Wv, Tk, need[6], bias=bv if need[7] else None)
         if cfg["self_attn"]:
             n3 = nq + nk + nv
-            if batched:  # one problem per parameter, each written straight into its .grad
-                dWq, dWk, dWv = (_weight_grad(g, q_in, W, Tq, nd) for g, W, nd in
-                                 ((dQ, Wq, need[2]), (dK, Wk, need[4]), (dV, Wv, need[6])))
-            else:
+            if not batched:
                 dW = L.gemm(L.GEMM_TN, dqkv, q_in, n3, d, Tq, lddq, q_in.stride(0), out_dtype=f32)
                 dWq, dWk, dWv = dW[:nq], dW[nq:nq + nk], dW[nq + nk:]
-            db = _colsum_overlapped(dqkv, Tq, n3, lddq, (bq, bk, bv))
-            dbq, dbk, dbv = db[:nq], db[nq:nq + nk], db[nq + nk:]
+                db = L.colsum(dqkv, Tq, n3, lddq)
+                dbq, dbk, dbv = db[:nq], db[nq:nq + nk], db[nq + nk:]
             dq_in = _input_grad(dqkv, lddq, (Wq, Wk, Wv), Tq, d, dt, add_to=dres)  # accumulates into dres in place
             dkv_in = None
         else:
-            dWq = _weight_grad(dQ, q_in, Wq, Tq, need[2])
-            dbq = _colsum_overlapped(dQ, Tq, nq, lddq, (bq,))
-            if batched:
-                dWk, dWv = _weight_grad(dK, kv_in, Wk, Tk, need[4]), _weight_grad(dV, kv_in, Wv, Tk, need[6])
-            else:
+            if not batched:
+                dWq, dbq = _weight_grad(dQ, q_in, Wq, Tq, need[2], bias=bq)
                 dW = L.gemm(L.GEMM_TN, dkv, kv_in, nk + nv, d, Tk, lddk, kv_in.stride(0), out_dtype=f32)
                 dWk, dWv = dW[:nk], dW[nk:]
-            db = _colsum_overlapped(dkv, Tk, nk + nv, lddk, (bk, bv))
-            dbk, dbv = db[:nk], db[nk:]
+                db = L.colsum(dkv, Tk, nk + nv, lddk)
+                dbk, dbv = db[:nk], db[nk:]
             dq_in = _input_grad(dQ, lddq, (Wq,), Tq, d, dt, add_to=dres)  # accumulates into dres in place
             dkv_in = _input_grad(dkv, lddk, (Wk, Wv), Tk, d, dt)
         return dq_in, dkv_in, dWq, dbq, dWk, dbk, dWv, dbv, dWo, dbo, None

@@ -31,7 +31,6 @@ class GradBucketReducer:
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.active = self.world > 1 or (always_reduce and dist.is_initialized())
-        self.joins_side_stream = True  # see ops._colsum_overlapped: _gather_late joins before it reads
         self.params = [p for p in params if p.requires_grad]
         seen, uniq = set(), []
         for p in self.params:
@@ -85,9 +84,6 @@ class GradBucketReducer:
                 grads.append(p.grad)
             off += n
         if views:
-            if views[0].is_cuda:
-                from . import ops
-                ops.join_side_stream()  # bias gradients may still be in flight on the second stream
             torch._foreach_copy_(views, grads)
             off = 0
             for p in plist:
@@ -104,6 +100,20 @@ class GradBucketReducer:
                 self._gather_late(bi)
                 self._handles.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         return hook
+
+    def bucket_view(self, p):
+        """The slice of its bucket that holds the gradient of p, for producers that write a gradient in place
+        (ops.batched_weight_grads writes bias gradients there and then calls mark_ready); None when gradients
+        are staged through host copies or nothing is reduced (the caller then allocates a tensor of its own)."""
+        if not self.active or self._staged:
+            return None
+        flat, plist = self.buckets[self._bucket_of[p.data_ptr()]]
+        off = 0
+        for q in plist:
+            if q is p:
+                return flat[off:off + p.numel()].view(p.shape)
+            off += q.numel()
+        return None
 
     def mark_ready(self, params):
         """Cue for gradients that were written into the bucket views directly instead of being

@@ -179,23 +179,28 @@ def test_gemm_grouped_tn(L, case):
     rn = lambda *shape: torch.randn(shape, device=DEV, generator=g).to(torch.bfloat16)
     probs, refs = [], []
 
-    def add(M, N, K, acc, a_pad=0):
+    def add(M, N, K, acc, a_pad=0, colsum=None):
+        """colsum: None (no column sums wanted), False (written), True (accumulated into)."""
         A_full, B = rn(K, M + a_pad), rn(K, N)
         A = A_full[:, a_pad:]  # a column slice of a wider buffer, like dq|dk|dv
         C = torch.randn((M, N), device=DEV, generator=g) if acc else torch.full((M, N), float("nan"), device=DEV)
         refs.append((C, (C.double() if acc else 0) + A.double().t() @ B.double()))
-        probs.append((A, B, C, M, N, K, A_full.stride(0), N, N, acc))
+        cs = None
+        if colsum is not None:
+            cs = torch.randn(M, device=DEV, generator=g) if colsum else torch.full((M,), float("nan"), device=DEV)
+            refs.append((cs, (cs.double() if colsum else 0) + A.double().sum(0)))
+        probs.append((A, B, C, M, N, K, A_full.stride(0), N, N, acc, cs, bool(colsum)))
 
     if case == "split_all":
-        add(512, 512, 3000, False); add(512, 512, 3000, True, a_pad=1024); add(2048, 512, 3000, True)
-        add(8, 264, 1000, False); add(520, 2048, 2999, False, a_pad=8)
+        add(512, 512, 3000, False, colsum=False); add(512, 512, 3000, True, a_pad=1024, colsum=True)
+        add(2048, 512, 3000, True); add(8, 264, 1000, False, colsum=False); add(520, 2048, 2999, False, a_pad=8, colsum=True)
     elif case == "full_round_and_tail":
         for i in range(20):
-            add(2048, 512, 1100, i % 2 == 0)
-        add(1000, 264, 1100, False)
+            add(2048, 512, 1100, i % 2 == 0, colsum=(None, False, True)[i % 3])
+        add(1000, 264, 1100, False, colsum=False)
     else:
         for i in range(60):
-            add(256 + 8 * (i % 3), 264, 200 + i, i % 3 == 0)
+            add(256 + 8 * (i % 3), 264, 200 + i, i % 3 == 0, colsum=(False, True, None)[i % 3])
     L.gemm_grouped_tn(probs)
     for i, (C, ref) in enumerate(refs):
         assert rel_err(C, ref) <= 1e-5, (case, i)
@@ -830,7 +835,9 @@ def test_full_size_weight_gradients_layernorm_and_adam(L):
         M, N = A.shape[1], B_.shape[1]
         C = torch.randn((M, N), device=DEV, generator=g) if acc else torch.full((M, N), float("nan"), device=DEV)
         refs.append((C, (C.double() if acc else 0) + A.double().t() @ B_.double()))
-        probs.append((A, B_, C, M, N, T, A.stride(0), B_.stride(0), N, acc))
+        cs = torch.full((M,), float("nan"), device=DEV)  # the bias gradient that goes with the weight gradient
+        refs.append((cs, A.double().sum(0)))
+        probs.append((A, B_, C, M, N, T, A.stride(0), B_.stride(0), N, acc, cs, False))
     L.gemm_grouped_tn(probs)
     for i, (C, ref) in enumerate(refs):
         assert rel_err(C, ref) <= 2e-5, i
