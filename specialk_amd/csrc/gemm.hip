@@ -1059,6 +1059,77 @@ __global__ __launch_bounds__(256) void grouped_reduce_kernel(GroupArgs g) {
 }
 }  // namespace b16x
 
+// ============================================================================ bf16, few rows, whole K in LDS
+// The decode step's projections: a few hundred rows (sentences x beams) against a 512-deep weight.  With a
+// handful of tiles per launch every tiled kernel above is a serial chain of K-steps, each exposing a load
+// latency (12 us per launch whatever the width).  Here a block owns a 32 x 64 output tile and requests ALL of
+// its operands at once — 32 + 64 rows of K elements, at most 96 KiB, straight into LDS — waits once, and then
+// multiplies out of LDS: one memory latency per launch instead of one per K-step.
+// LDS image: [row][K], row r's 16-byte chunk c at chunk position c ^ (r & 15) (applied to the source address;
+// the direct-to-LDS destination is lane-linear), so that the 16 rows of a fragment read hit 16 different
+// 16-byte slots.  Four waves; wave w owns output columns 16 w .. 16 w + 15 of the tile (two MFMA tiles).
+namespace b16s {
+constexpr int SM = 32, SN = 64, MAX_K = 512;
+using b16g::gbl_ptr_t;
+using b16g::lds_ptr_t;
+
+template <typename TOut>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tile_n = blockIdx.x % p.tiles_n, tile_m = blockIdx.x / p.tiles_n;
+  const int m0 = tile_m * SM, n0 = tile_n * SN;
+  const int K = p.K, cr = K >> 3;          // 16-byte chunks per row (a power of two >= 16: host)
+  const int row_bytes = K * 2;
+  char* ldsA = smem;
+  char* ldsB = smem + SM * row_bytes;
+  const bf16_t* A = (const bf16_t*)p.A;
+  const bf16_t* B = (const bf16_t*)p.B;
+  // all loads: linear chunk index i = 256 * it + tid covers first A's SM * cr chunks, then B's SN * cr
+  const int total = (SM + SN) * cr;
+  for (int it = 0; it * 256 < total; ++it) {
+    const int i = it * 256 + tid;            // total is a multiple of 256 (cr >= 16): no partial wave
+    const bool isB = i >= SM * cr;
+    const int j = isB ? i - SM * cr : i;
+    const int r = j / cr, pos = j - r * cr;
+    const int c = pos ^ (r & 15);
+    const int64_t grow = isB ? min(n0 + r, p.N - 1) : min(m0 + r, p.M - 1);  // clamped rows are never stored
+    const bf16_t* src = (isB ? B + grow * p.ldb : A + grow * p.lda) + 8 * c;
+    char* dst = (isB ? ldsB : ldsA) + (int64_t)(j - lane) * 16;  // wave-uniform base: this wave's 64 chunks are contiguous
+    __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)dst, 16, 0, 0);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+
+  const int l15 = lane & 15, g = lane >> 4;
+  f32x4_t acc[2] = {f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}};
+  const char* a0 = ldsA + l15 * row_bytes;
+  const char* a1 = ldsA + (16 + l15) * row_bytes;
+  const char* b0 = ldsB + (16 * wave + l15) * row_bytes;
+  const int nk = K >> 5;
+#pragma unroll 4
+  for (int kk = 0; kk < nk; ++kk) {
+    const int off = ((4 * kk + g) ^ l15) << 4;   // rows l15, 16 + l15 and 16 w + l15 share (row & 15) = l15
+    const bf16x8_t fa0 = *(const bf16x8_t*)(a0 + off);
+    const bf16x8_t fa1 = *(const bf16x8_t*)(a1 + off);
+    const bf16x8_t fb = *(const bf16x8_t*)(b0 + off);
+    acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb, fa0, acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb, fa1, acc[1], 0, 0, 0);
+  }
+  // C^T tiles: lane owns output row 16 mi + l15 and columns 16 w + 4 g + r
+  const int col = n0 + 16 * wave + 4 * g;
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi) {
+    const int row = m0 + 16 * mi + l15;
+    if (row >= p.M) continue;
+    float v[4] = {acc[mi][0], acc[mi][1], acc[mi][2], acc[mi][3]};
+    write_cols<TOut, bf16_t, 4>(p, v, row, col, -1);
+  }
+}
+}  // namespace b16s
+
 // ============================================================================ fp32
 namespace f32 {
 constexpr int BK = 16;
@@ -1450,6 +1521,30 @@ static int gemm_one(int layout, const void* A, const void* B, void* C, const voi
   p.k_per_split = kps;
   if (splits > 1) p.ws = (float*)workspace;
 
+  // Few rows against a short contraction (the decode step's projections): the whole-K-in-LDS kernel.
+  {
+    const char* e = getenv("SKHIP_GEMM_SKINNY");
+    const bool allowed = !(e && e[0] == '0') && !(env_big && env_big[0] == '1') && !(env_staged && env_staged[0] == '1');
+    if (allowed && in_dtype == SK_BF16 && layout == SK_GEMM_NT && fast && M <= 1024 && K >= 128 && K <= b16s::MAX_K &&
+        (K & (K - 1)) == 0 && N % b16s::SN == 0 && !(epilogue & ~(SK_EPI_BIAS | SK_EPI_RELU))) {
+      p.tiles_m = (int)((M + b16s::SM - 1) / b16s::SM);
+      p.tiles_n = (int)(N / b16s::SN);
+      p.k_per_split = (int)K;
+      const size_t lds = (size_t)(b16s::SM + b16s::SN) * K * 2;
+      const dim3 sgrid((unsigned)(p.tiles_m * p.tiles_n));
+      if (out_dtype == SK_BF16) {
+        int rc = sk_allow_big_lds(b16s::gemm_kernel<bf16_t>, lds);
+        if (rc) return rc;
+        hipLaunchKernelGGL((b16s::gemm_kernel<bf16_t>), sgrid, dim3(256), lds, stream, p);
+      } else {
+        int rc = sk_allow_big_lds(b16s::gemm_kernel<float>, lds);
+        if (rc) return rc;
+        hipLaunchKernelGGL((b16s::gemm_kernel<float>), sgrid, dim3(256), lds, stream, p);
+      }
+      SK_CHECK_LAUNCH("skhip_gemm(few rows)");
+      return SK_OK;
+    }
+  }
   dim3 grid((unsigned)tiles, 1, (unsigned)splits);
 #define LAUNCH_B16(AT, BT, TO)                                                                              \
   (fast ? (use_staged ? launch_gemm(b16::gemm_kernel<AT, BT, TO, true>, grid, b16::SMEM_BYTES, stream, p)   \
