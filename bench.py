@@ -226,6 +226,92 @@ def cpu_baseline(cfg, seconds_budget=25.0):
                        f"{n_sent} sentences/step ({tok} target tokens), lengths U[{cfg['lo']},{cfg['hi']}], {dt:.1f} s")
 
 
+def decode_leg(device, n_batches=10, batch=128, beam=5, max_len=150, copy_task_steps=600):
+    """Beam-search decode throughput at the style-transfer inference shape (beam 5, 128 sentences per batch, source
+    lengths U[12,42], at most 150 target tokens; lib/transformer/Translator.py:55-226), inputs resident in HBM.
+
+    "worst_case": the benchmark architecture (6+6, d 512) with random weights — such a network never emits EOS, so
+    every sentence decodes all 150 steps with all 640 beams alive.  "copy_task": a 2+2-layer network of the same
+    width, trained here (untimed) with this package's own training step on a synthetic copy task until it
+    reproduces its input, so that hypotheses end with EOS at about the source length (the 6+6 post-LN stack does
+    not leave that task's initial plateau within a few thousand steps, in fp32 or bf16).
+    HBM roofline of the worst case: algorithmic bytes of one step at history length t — self-attention keys and
+    values of t positions for every beam row, encoder-side keys / values once per sentence, the decoder's and
+    generator's bf16 weights once, the fp32 log-probabilities written once and read twice (normalisation, top-k) —
+    summed over the steps, divided by the time."""
+    from specialk_amd import ops
+    from specialk_amd.decode import BeamDecoder
+    out = {}
+    g = torch.Generator().manual_seed(3)
+
+    def run(m, vocab_used, n_batches):
+        dec = BeamDecoder(m, beam, max_len)
+        sent = tok = exact = 0
+        steps_bytes = 0.0
+        dt = 0.0
+        for i in range(n_batches + 1):  # batch 0 warms up
+            s, sp = make_batch(g, batch, 12, 42, vocab_used)
+            s, sp = s.to(device), sp.to(device)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            hyps, _ = dec.run(s, sp, 1)
+            torch.cuda.synchronize()
+            if i == 0:
+                continue
+            dt += time.perf_counter() - t0
+            sent += len(hyps)
+            tok += sum(len(h[0]) for h in hyps)
+            src = s.cpu().tolist()
+            exact += sum(1 for row, h in zip(src, hyps) if [t for t in row[1:] if t != 0] == list(h[0]))
+            steps_bytes += decode_step_bytes(m, batch, beam, int((s != PAD).sum(1).max()), dec.last_steps)
+        return sent, tok, exact, dt, steps_bytes
+
+    cfg = dict(CONFIGS["cfg2"]); cfg["hi"] = max_len
+    m, _ = build(cfg, torch.bfloat16, device)
+    m.eval()
+    sent, tok, exact, dt, nbytes = run(m, cfg["vocab"], n_batches)
+    out["worst_case"] = dict(model="6+6 d512 FFN2048 V35000, random weights (no EOS: all 150 steps, 640 beams alive)",
+                             sentences=sent, sentences_per_sec=round(sent / dt, 1), tokens_per_sec=round(tok / dt, 1),
+                             mean_output_length=round(tok / sent, 1), ms_per_step=round(dt / (n_batches * max_len) * 1e3, 4),
+                             roofline=dict(bound="hbm", achieved=round(nbytes / dt / 1e9, 1), peak=8000.0, unit="GB/s",
+                                           frac=round(nbytes / dt / 8e12, 4), traffic=None,
+                                           algorithmic_bytes_per_step=round(nbytes / (n_batches * max_len))))
+    del m
+    if copy_task_steps:
+        cfg2 = dict(cfg); cfg2["n_layers"] = 2
+        m, opt = build(cfg2, torch.bfloat16, device)
+        opt.n_warmup_steps = 1500
+        ops.manual_seed(5)
+        for _ in range(copy_task_steps):
+            s_, sp_ = make_batch(g, 640, 12, 42, 2000)
+            train_step(m, opt, tuple(x.to(device) for x in (s_, sp_, s_, sp_)), None)
+        m.eval()
+        sent, tok, exact, dt, _ = run(m, 2000, n_batches)
+        out["copy_task"] = dict(model=f"2+2 d512 FFN2048 V35000 trained {copy_task_steps} steps on a synthetic copy task",
+                                sentences=sent, sentences_per_sec=round(sent / dt, 1), tokens_per_sec=round(tok / dt, 1),
+                                mean_output_length=round(tok / sent, 1), exact_copies=exact)
+    out["config"] = dict(beam=beam, batch=batch, src_len="U[12,42]", max_token_seq_len=max_len, dtype="bf16")
+    return out
+
+
+def decode_step_bytes(m, n, bm, Ls, steps):
+    """Algorithmic HBM bytes of `steps` decode steps of a batch (see decode_leg)."""
+    dec = m.decoder
+    NL = len(dec.layer_stack)
+    a = dec.layer_stack[0].slf_attn
+    H, dk, dv = a.n_head, a.d_k, a.d_v
+    d = dec.tgt_word_emb.weight.shape[1]
+    F = dec.layer_stack[0].pos_ffn.w_1.weight.shape[0]
+    V = m.generator.weight.shape[0]
+    R = n * bm
+    kv_row = H * (dk + dv) * 2                                   # bytes of one cached position (bf16)
+    # per layer: self-attention q, k, v, output projections; cross-attention q and output projections; the two FFN matrices
+    weights = NL * (3 * H * dk * d + 3 * H * dv * d + 2 * d * F) * 2 + V * d * 2
+    per_step_fixed = weights + NL * n * Ls * kv_row + 3 * R * V * 4
+    hist = NL * R * kv_row * (steps * (steps + 1) / 2)           # sum over t = 1..steps of t positions
+    return steps * per_step_fixed + hist
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -236,6 +322,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--padded", action="store_true", help="keep padding rows (the reference's tensor shapes)")
+    ap.add_argument("--no-decode", action="store_true", help="skip the beam-decode leg")
     args = ap.parse_args()
 
     # stdout carries exactly one line, the result: libraries that write to file descriptor 1 themselves (RCCL
@@ -326,6 +413,10 @@ def main():
             out["roofline"] = gemm_roofline(m, opt, batches[0], 3)
             if args.config != "cfg2" or args.padded:  # the counter passes were taken on the default workload
                 out["roofline"]["traffic"] = out["roofline"]["traffic_source"] = None
+        if not args.no_decode and world == 1 and args.config == "cfg2" and args.dtype == "bf16":
+            del m, opt
+            torch.cuda.empty_cache()
+            out["decode"] = decode_leg(device)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(cfg)
     if rank == 0:

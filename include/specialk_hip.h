@@ -319,6 +319,21 @@ int skhip_beam_topk(const float* logits, const float* scores_in, float* scores_o
                     int32_t* prev_out, int32_t* tok_out, void* ws, int n_sent, int bm, int64_t V,
                     int first_step, int normalize, void* stream);
 
+/* The bookkeeping between two decoder steps of the beam search, for all sentences, in one launch:
+ * Beam.advance's state update (lib/transformer/Beam.py:64-79: scores, prev_ks, next_ys, the EOS test on the
+ * best beam), the active-sentence bookkeeping of Translator.py:142-168 and the next step's decoder inputs
+ * (Translator.py:113-128).  R = n_sent*bm rows.  Step number t is read per row from cur_len[r] (and advanced),
+ * so that a captured step can be replayed.  new_scores / prev / new_tok: outputs of skhip_beam_topk.
+ * scores [n_sent][bm] is overwritten for sentences that had not finished; ys [max_len+1][R], ks [max_len][R]
+ * record tokens and back-pointers; done / length [n_sent] int32; *n_done counts finished sentences.
+ * hist_in / hist_out [R][Tc]: the history-row table of skhip_decode_attn before / after re-parenting.
+ * tok, pos (int64 [R]), row_pad (uint8 [R]) and pad_hist[r][t] are the inputs of step t+1.            */
+int skhip_beam_update(const float* new_scores, const int32_t* prev, const int32_t* new_tok, float* scores,
+                      int32_t* ys, int32_t* ks, int32_t* done, int32_t* length, int32_t* n_done,
+                      int32_t* cur_len, int64_t* tok, int64_t* pos, uint8_t* row_pad, uint8_t* pad_hist,
+                      const int32_t* hist_in, int32_t* hist_out, int n_sent, int bm, int Tc, int max_len,
+                      int pad_id, int eos_id, void* stream);
+
 /* Reorder a cache after a beam step: dst[r] = src[src_row[r]] for rows of `row_elems`
  * elements (replaces re-building dec_seq from back-pointers every step, Beam.py:90-110,
  * and the index_select compaction, Translator.py:65-101).                                  */

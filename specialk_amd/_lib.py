@@ -22,7 +22,7 @@ EXPORTS = [
     "skhip_version", "skhip_last_error", "skhip_init", "skhip_gemm", "skhip_gemm_grouped_tn", "skhip_colsum", "skhip_colsum_noalloc", "skhip_attn_fwd",
     "skhip_attn_bwd", "skhip_attn_varlen_fwd", "skhip_attn_varlen_bwd", "skhip_add_ln_fwd", "skhip_add_ln_bwd_ws_floats", "skhip_add_ln_bwd", "skhip_embed_fwd",
     "skhip_embed_bwd", "skhip_pack_plan", "skhip_xent_fwd_bwd", "skhip_adam_multi", "skhip_cast_multi", "skhip_cast2d_multi", "skhip_convert",
-    "skhip_decode_attn", "skhip_beam_topk_ws_bytes", "skhip_beam_topk", "skhip_gather_rows",
+    "skhip_decode_attn", "skhip_beam_topk_ws_bytes", "skhip_beam_topk", "skhip_beam_update", "skhip_gather_rows",
     "skhip_softmax_rows", "skhip_conv_windows", "skhip_cnn_head", "skhip_collate",
 ]
 
@@ -72,6 +72,7 @@ def load():
     lib.skhip_convert.argtypes = [c_p, c_p, c_i64, c_int, c_int, c_p]
     lib.skhip_decode_attn.argtypes = [c_p] * 9 + [c_i64] + [c_int] * 6 + [c_i64, c_i64, c_f32, c_int, c_int, c_p]
     lib.skhip_beam_topk.argtypes = [c_p] * 6 + [c_int, c_int, c_i64, c_int, c_int, c_p]
+    lib.skhip_beam_update.argtypes = [c_p] * 16 + [c_int] * 6 + [c_p]
     lib.skhip_gather_rows.argtypes = [c_p] * 3 + [c_i64] * 4 + [c_int, c_p]
     for name in EXPORTS:
         getattr(lib, name)  # AttributeError here means header and library disagree
@@ -390,18 +391,34 @@ def decode_attn(q, Kc, Vc, out, R, H, length, Lmax, dk, dv, ldq, ldo, scale, kv_
     _check(rc, "skhip_decode_attn")
 
 
-def beam_topk(logits, scores_in, n_sent, bm, first_step, normalize=True):
+def beam_topk(logits, scores_in, n_sent, bm, first_step, normalize=True, out=None):
+    """out: optional (scores_out, prev, tok) to write into."""
     lib = load()
     V = logits.shape[-1]
     dev = logits.device
-    scores_out = torch.empty((n_sent, bm), dtype=torch.float32, device=dev)
-    prev = torch.empty((n_sent, bm), dtype=torch.int32, device=dev)
-    tok = torch.empty((n_sent, bm), dtype=torch.int32, device=dev)
+    if out is not None:
+        scores_out, prev, tok = out
+    else:
+        scores_out = torch.empty((n_sent, bm), dtype=torch.float32, device=dev)
+        prev = torch.empty((n_sent, bm), dtype=torch.int32, device=dev)
+        tok = torch.empty((n_sent, bm), dtype=torch.int32, device=dev)
     ws = workspace(int(lib.skhip_beam_topk_ws_bytes(n_sent, bm, V)))
     rc = lib.skhip_beam_topk(_ptr(logits), _ptr(scores_in), _ptr(scores_out), _ptr(prev), _ptr(tok), _ptr(ws),
                              n_sent, bm, V, int(first_step), int(normalize), _stream())
     _check(rc, "skhip_beam_topk")
     return scores_out, prev, tok
+
+
+def beam_update(new_scores, prev, new_tok, scores, ys, ks, done, length, n_done, cur_len, tok, pos, row_pad, pad_hist,
+                hist_in, hist_out, n_sent, bm, Tc, max_len, pad_id, eos_id):
+    """The state update between two beam-search steps (see the header); every argument is a device tensor."""
+    assert done.dtype == length.dtype == n_done.dtype == cur_len.dtype == torch.int32
+    assert tok.dtype == pos.dtype == torch.int64 and row_pad.dtype == pad_hist.dtype == torch.uint8
+    rc = load().skhip_beam_update(_ptr(new_scores), _ptr(prev), _ptr(new_tok), _ptr(scores), _ptr(ys), _ptr(ks), _ptr(done),
+                                  _ptr(length), _ptr(n_done), _ptr(cur_len), _ptr(tok), _ptr(pos), _ptr(row_pad),
+                                  _ptr(pad_hist), _ptr(hist_in), _ptr(hist_out), n_sent, bm, Tc, max_len, pad_id, eos_id,
+                                  _stream())
+    _check(rc, "skhip_beam_update")
 
 
 def gather_rows(src, dst, src_row, n_rows, row_elems, src_stride, dst_stride):

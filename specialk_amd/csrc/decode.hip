@@ -322,6 +322,49 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const char* __restrict
   }
 }
 
+// ------------------------------------------------------------------ beam state update
+// Everything Beam.advance / Translator.collect_active_inst_idx_list / prepare_beam_dec_seq do between two
+// decoder steps (lib/transformer/Beam.py:46-79, Translator.py:113-168), for all sentences, in one launch with
+// every step-dependent quantity read from and written to device memory (so a step can be replayed from a
+// captured graph).  One wave per beam row r = (sentence s, beam b); t = cur_len[r] is the step just taken:
+//   scores[s] <- new_scores[s] unless sentence s had finished; back-pointers and tokens recorded in ks[t-1], ys[t];
+//   sentence finishes (length[s] = t, done[s] = 1, *n_done += 1) when its best beam's token is EOS;
+//   history table re-parented: hist_out[r][0..t) = hist_in[s*bm + prev[s][b]][0..t), hist_out[r][t] = r;
+//   inputs of the next step: tok[r], pos[r] = t + 1, row_pad[r] and pad_hist[r][t] = (token is PAD), cur_len[r] = t + 1.
+__global__ __launch_bounds__(64) void beam_update_kernel(const float* __restrict__ new_scores, const int32_t* __restrict__ prev,
+                                                         const int32_t* __restrict__ new_tok, float* __restrict__ scores,
+                                                         int32_t* __restrict__ ys, int32_t* __restrict__ ks,
+                                                         int32_t* __restrict__ done, int32_t* __restrict__ length,
+                                                         int32_t* __restrict__ n_done, int32_t* __restrict__ cur_len,
+                                                         int64_t* __restrict__ tok, int64_t* __restrict__ pos,
+                                                         uint8_t* __restrict__ row_pad, uint8_t* __restrict__ pad_hist,
+                                                         const int32_t* __restrict__ hist_in, int32_t* __restrict__ hist_out,
+                                                         int n_sent, int bm, int Tc, int max_len, int pad_id, int eos_id) {
+  const int r = blockIdx.x, lane = threadIdx.x;
+  const int s = r / bm, b = r - s * bm;
+  const int t = cur_len[r];
+  if (t < 1 || t > max_len) return;  // past the last step (a replayed graph may overshoot): nothing to do
+  const int R = n_sent * bm;
+  const int p = prev[r], w = new_tok[r];
+  const int32_t* hin = hist_in + (int64_t)(s * bm + p) * Tc;
+  int32_t* hout = hist_out + (int64_t)r * Tc;
+  for (int j = lane; j < t; j += 64) hout[j] = hin[j];
+  if (lane == 0) {
+    const bool is_pad = w == pad_id;
+    if (t < Tc) { hout[t] = r; pad_hist[(int64_t)r * Tc + t] = is_pad; }
+    tok[r] = w;
+    pos[r] = t + 1;
+    row_pad[r] = is_pad;
+    cur_len[r] = t + 1;
+    ks[(int64_t)(t - 1) * R + r] = p;
+    ys[(int64_t)t * R + r] = w;
+    if (b == 0 && !done[s]) {
+      for (int k = 0; k < bm; ++k) scores[s * bm + k] = new_scores[s * bm + k];
+      if (w == eos_id) { length[s] = t; done[s] = 1; atomicAdd(n_done, 1); }
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int skhip_decode_attn(const void* q, void* Kc, void* Vc, void* out, const int32_t* kv_len,
@@ -336,8 +379,8 @@ extern "C" int skhip_decode_attn(const void* q, void* Kc, void* Vc, void* out, c
   if (R == 0) return SK_OK;
   SK_CHECK_ARG(q && Kc && Vc && out, "skhip_decode_attn: null pointer");
   SK_CHECK_ARG(!new_k == !new_v, "skhip_decode_attn: new_k and new_v come together");
-  SK_CHECK_ARG(!new_k || (kv_row_div == 1 && !kv_len && len >= 1 && ld_new >= (int64_t)n_head * (dk > dv ? dk : dv)),
-               "skhip_decode_attn: appending needs one cache row per query row, a common length >= 1 and ld_new >= row width");
+  SK_CHECK_ARG(!new_k || (kv_row_div == 1 && (kv_len || len >= 1) && ld_new >= (int64_t)n_head * (dk > dv ? dk : dv)),
+               "skhip_decode_attn: appending needs one cache row per query row, a length >= 1 and ld_new >= row width");
   unsigned blocks = (unsigned)(((int64_t)R * n_head + 3) / 4);
   const int vn = dtype == SK_BF16 ? 8 : 4;
   const int vec_k = (dk % vn == 0) && ((uintptr_t)Kc % 16 == 0);  // key rows start on 16-byte boundaries
@@ -407,5 +450,22 @@ extern "C" int skhip_gather_rows(const void* src, void* dst, const int32_t* src_
   else
     hipLaunchKernelGGL((gather_rows_kernel<2>), grid, dim3(256), 0, stream, (const char*)src, (char*)dst, src_row, rb, ss, ds);
   SK_CHECK_LAUNCH("skhip_gather_rows");
+  return SK_OK;
+}
+
+extern "C" int skhip_beam_update(const float* new_scores, const int32_t* prev, const int32_t* new_tok, float* scores,
+                                 int32_t* ys, int32_t* ks, int32_t* done, int32_t* length, int32_t* n_done,
+                                 int32_t* cur_len, int64_t* tok, int64_t* pos, uint8_t* row_pad, uint8_t* pad_hist,
+                                 const int32_t* hist_in, int32_t* hist_out, int n_sent, int bm, int Tc, int max_len,
+                                 int pad_id, int eos_id, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SK_CHECK_ARG(n_sent >= 0 && bm >= 1 && Tc >= 1 && max_len >= 1, "skhip_beam_update: bad shape");
+  if (n_sent == 0) return SK_OK;
+  SK_CHECK_ARG(new_scores && prev && new_tok && scores && ys && ks && done && length && n_done && cur_len && tok && pos &&
+               row_pad && pad_hist && hist_in && hist_out && hist_in != hist_out, "skhip_beam_update: null or aliased pointer");
+  hipLaunchKernelGGL(beam_update_kernel, dim3((unsigned)(n_sent * bm)), dim3(64), 0, stream, new_scores, prev, new_tok, scores,
+                     ys, ks, done, length, n_done, cur_len, tok, pos, row_pad, pad_hist, hist_in, hist_out, n_sent, bm, Tc,
+                     max_len, pad_id, eos_id);
+  SK_CHECK_LAUNCH("skhip_beam_update");
   return SK_OK;
 }

@@ -15,6 +15,8 @@ Reference quirks kept: the generator is applied without x_logit_scale (Translato
 a sentence ends when its TOP beam emits EOS, other beams keep extending past EOS; no length
 penalty; step 1 only expands beam 0.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -24,10 +26,32 @@ from .core import constants as Constants
 
 
 class BeamDecoder:
-    def __init__(self, model, beam_size, max_token_seq_len):
+    def __init__(self, model, beam_size, max_token_seq_len, use_graph=None):
         self.model = model
         self.bm = int(beam_size)
         self.max_len = int(max_token_seq_len)
+        # replay pairs of steps from a captured HIP graph (SK_DECODE_GRAPH=0: launch every step from the host)
+        self.use_graph = os.environ.get("SK_DECODE_GRAPH", "1") != "0" if use_graph is None else bool(use_graph)
+
+    _capture_streams = {}
+
+    @classmethod
+    def _capture_pair(cls, step, cur, dev):
+        """Capture two consecutive steps (history table cur -> cur ^ 1 -> cur) into a graph.  The stream of the
+        capture is kept per device and gets its kernel workspace before the capture starts, so that no
+        allocation that outlives the graph comes from the graph's private pool."""
+        stream = cls._capture_streams.get(dev)
+        if stream is None:
+            stream = cls._capture_streams[dev] = torch.cuda.Stream(dev)
+        stream.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(stream):
+            L.workspace()
+        torch.cuda.current_stream(dev).wait_stream(stream)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=stream):
+            step(False, cur)
+            step(False, cur ^ 1)
+        return graph
 
     def _w(self, p, dtype):
         w = ops.compute_weight(p, dtype)
@@ -73,18 +97,26 @@ class BeamDecoder:
         Tc = (Tmax + 15) // 16 * 16
         Kc = torch.zeros((NL, R, Tc, H * dk), dtype=dt, device=dev)
         Vc = torch.zeros((NL, R, Tc, H * dv), dtype=dt, device=dev)
+        i32 = dict(dtype=torch.int32, device=dev)
         pad_hist = torch.zeros((R, Tc), dtype=torch.uint8, device=dev)
-        hist = [torch.zeros((R, Tc), dtype=torch.int32, device=dev) for _ in range(2)]
-        own_row = torch.arange(R, dtype=torch.int32, device=dev)
-        cur = 0
+        hist = [torch.zeros((R, Tc), **i32) for _ in range(2)]
+        hist[0][:, 0] = torch.arange(R, **i32)
 
+        # Beam state and the inputs of the next step live on the device and are advanced by one kernel per step
+        # (skhip_beam_update), including the step counter (cur_len): a step's launches do not depend on the
+        # step number, so pairs of steps (the history table is double buffered) are captured in a graph once
+        # per batch and replayed.
         scores = torch.zeros((n, bm), dtype=torch.float32, device=dev)
-        ys = torch.zeros((Tmax + 1, n, bm), dtype=torch.int32, device=dev)
-        ks = torch.zeros((Tmax, n, bm), dtype=torch.int32, device=dev)
-        done = torch.zeros(n, dtype=torch.bool, device=dev)
-        length = torch.full((n,), Tmax, dtype=torch.int32, device=dev)
+        new_scores = torch.empty((n, bm), dtype=torch.float32, device=dev)
+        prev, new_tok = torch.empty((n, bm), **i32), torch.empty((n, bm), **i32)
+        ys = torch.zeros((Tmax + 1, n, bm), **i32)
+        ks = torch.zeros((Tmax, n, bm), **i32)
+        done, n_done = torch.zeros(n, **i32), torch.zeros(1, **i32)
+        length = torch.full((n,), Tmax, **i32)
+        cur_len = torch.ones(R, **i32)
         tok = torch.full((R,), Constants.SOS, dtype=torch.int64, device=dev)
-        sent_base = (torch.arange(n, device=dev, dtype=torch.int32) * bm)[:, None]
+        pos = torch.ones(R, dtype=torch.int64, device=dev)
+        row_pad = torch.zeros(R, dtype=torch.uint8, device=dev)
         gen_w = self._w(model.generator.weight, dt)
         V = gen_w.shape[0]
         word_emb, pos_tab = dec.tgt_word_emb.weight.detach(), dec.position_enc.weight.detach()
@@ -103,55 +135,56 @@ class BeamDecoder:
             return L.gemm(L.GEMM_NT, x, w, R, w.shape[0], w.shape[1], x.stride(0), w.shape[1], out=out, ldc=ldc,
                           bias=lin.bias.detach(), epilogue=L.EPI_RELU if relu else 0, split_k=w.shape[1] >= 2048)
 
-        def add_ln(o, x, ln, row_pad):
+        def add_ln(o, x, ln):
             y, _, _ = L.add_ln_fwd(o, x, ln.weight.detach(), ln.bias.detach(), row_pad, ln.eps, 0.0, 0)
             return y
 
-        steps = 0
-        for t in range(1, Tmax + 1):
-            steps = t
-            pos = torch.full((R,), t, dtype=torch.int64, device=dev)
-            row_pad = tok.eq(Constants.PAD).to(torch.uint8)
-            pad_hist[:, t - 1] = row_pad
-            hist[cur][:, t - 1] = own_row
+        def step(first, cur):
+            """One decoder step on the newest position of every beam, then the beam update; reads the history
+            table hist[cur] and leaves the re-parented one in hist[cur ^ 1]."""
             x = L.embed_fwd(tok, pos, word_emb, pos_tab, dt)
             for li, layer in enumerate(layers):
                 a = layer.slf_attn
                 qkv = L.gemm(L.GEMM_NT, x, qkv_w[li], R, nq + nk + nv, d, x.stride(0), d, bias=qkv_b[li], split_k=False)
                 att = torch.empty((R, H * dv), dtype=dt, device=dev)
-                # the kernel takes position t-1's key / value from the projection and appends them to the caches
-                L.decode_attn(qkv, Kc[li], Vc[li], att, R, H, t, Tc, dk, dv, nq + nk + nv, H * dv, scale,
+                # the kernel takes the newest position's key / value from the projection and appends them to the caches
+                L.decode_attn(qkv, Kc[li], Vc[li], att, R, H, 0, Tc, dk, dv, nq + nk + nv, H * dv, scale, kv_len=cur_len,
                               key_pad=pad_hist, hist_row=hist[cur], new_k=qkv[:, nq:], new_v=qkv[:, nq + nk:],
                               ld_new=nq + nk + nv)
-                x = add_ln(proj(att, a.fc), x, a.layer_norm, row_pad)
+                x = add_ln(proj(att, a.fc), x, a.layer_norm)
                 a = layer.enc_attn
                 q = proj(x, a.w_qs)
                 L.decode_attn(q, crossK[li], crossV[li], att, R, H, Ls, Ls, dk, dv, H * dk, H * dv, scale,
                               key_pad=src_key_pad, kv_row_div=bm)
-                x = add_ln(proj(att, a.fc), x, a.layer_norm, row_pad)
+                x = add_ln(proj(att, a.fc), x, a.layer_norm)
                 f = layer.pos_ffn
                 hbuf = proj(x, f.w_1, relu=True)
-                x = add_ln(proj(hbuf, f.w_2), x, f.layer_norm, row_pad)
+                x = add_ln(proj(hbuf, f.w_2), x, f.layer_norm)
             logits = L.gemm(L.GEMM_NT, x, gen_w, R, V, d, d, d, out_dtype=torch.float32)
-            new_scores, prev, new_tok = L.beam_topk(logits, scores, n, bm, first_step=(t == 1))
+            L.beam_topk(logits, scores, n, bm, first_step=first, out=(new_scores, prev, new_tok))
             # finished sentences keep their final beam state (their Beam is no longer advanced)
-            keep = done[:, None]
-            scores = torch.where(keep, scores, new_scores)
-            ks[t - 1] = prev
-            ys[t] = new_tok
-            newly = (~done) & new_tok[:, 0].eq(Constants.EOS)
-            length = torch.where(newly, torch.full_like(length, t), length)
-            done = done | newly
-            # the host looks at the flag every fourth step only: a step past the end changes nothing
-            # (finished sentences keep their state) and costs less than a pipeline drain per step
-            if (t % 4 == 0 or t == Tmax) and bool(done.all()):
+            L.beam_update(new_scores, prev, new_tok, scores, ys, ks, done, length, n_done, cur_len, tok, pos, row_pad,
+                          pad_hist, hist[cur], hist[cur ^ 1], n, bm, Tc, Tmax, Constants.PAD, Constants.EOS)
+
+        step(True, 0)  # step 1 expands beam 0 only (Beam.py:51-54)
+        steps, cur = 1, 1
+        graph = None
+        if self.use_graph and Tmax >= 3:
+            graph = self._capture_pair(step, cur, dev)
+        # the host looks at the finished-sentence count every fourth step only: a step past the end changes nothing
+        # (finished sentences keep their state) and costs less than a pipeline drain per step
+        while steps < Tmax:
+            if graph is not None and steps + 2 <= Tmax:
+                graph.replay()
+                steps += 2
+            else:
+                step(False, cur)
+                cur ^= 1
+                steps += 1
+            if (steps % 4 <= 1 or steps == Tmax) and int(n_done.item()) == n:
                 break
-            # re-order the history table by back-pointer: new row (s, b) <- old row (s, prev[s, b])
-            src_row = (sent_base + prev).reshape(-1).contiguous()
-            nxt = cur ^ 1
-            L.gather_rows(hist[cur].view(torch.float32), hist[nxt].view(torch.float32), src_row, R, Tc, Tc, Tc)
-            cur = nxt
-            tok = new_tok.reshape(-1).to(torch.int64)
+        del graph
+        self.last_steps = steps
         if was_training:
             model.train()
 
