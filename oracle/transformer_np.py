@@ -15,8 +15,48 @@ dicts keyed by the reference's state_dict names.  Citations are to files under
 """
 import numpy as np
 
+import contextlib
+
 PAD, UNK, SOS, EOS, BLO = 0, 1, 2, 3, 4  # core/constants.py:6-10
 LN_EPS = 1e-5                             # nn.LayerNorm default used by lib/transformer/SubLayers.py:30,75
+
+# ----------------------------------------------------------------------------- bf16 storage mode
+# The reference computes in fp32 throughout.  The accelerated path can keep activations, activation gradients
+# and the matrices' working copies in bfloat16 (fp32 accumulation, fp32 statistics, fp32 parameter gradients).
+# Inside `with bf16_storage():` the functions below round to bfloat16 (nearest even) at exactly those points —
+# every tensor such a path writes to memory in bf16 — and are otherwise unchanged, so the result is what the
+# reference's arithmetic gives under that storage format: the yardstick for a bf16 run.  Outside the context
+# nothing is rounded and the module is the fp32 / fp64 restatement that the golden vectors pin.
+_bf16 = False
+
+
+@contextlib.contextmanager
+def bf16_storage():
+    global _bf16
+    old, _bf16 = _bf16, True
+    try:
+        yield
+    finally:
+        _bf16 = old
+
+
+def round_bf16(x):
+    x32 = np.ascontiguousarray(x, dtype=np.float32)
+    u = x32.view(np.uint32)
+    r = (u + (((u >> 16) & 1) + 0x7FFF)) & np.uint32(0xFFFF0000)
+    out = np.where(np.isnan(x32), x32, r.view(np.float32))
+    return out.astype(x.dtype) if isinstance(x, np.ndarray) else out
+
+
+def _rt(x):
+    """Round a stored activation / activation gradient to bf16 in bf16-storage mode."""
+    return round_bf16(x) if _bf16 else x
+
+
+def _wt(w, key):
+    """A matrix as the GEMMs read it: its bf16 working copy in bf16-storage mode."""
+    return round_bf16(w[key]) if _bf16 else w[key]
+
 
 
 # ----------------------------------------------------------------------------- data
@@ -85,13 +125,17 @@ def sdpa_fwd(q, k, v, mask, temperature):
         m = s.max(-1, keepdims=True)
         e = np.exp(s - m)
         p = e / e.sum(-1, keepdims=True)
+        if _bf16:  # the un-normalised probabilities are the bf16 operand of P.V; the row sum stays fp32
+            return np.matmul(round_bf16(e), v) / e.sum(-1, keepdims=True), p
     return np.matmul(p, v), p
 
 
-def sdpa_bwd(q, k, v, p, dout, temperature):
-    dv = np.matmul(p.transpose(0, 2, 1), dout)
+def sdpa_bwd(q, k, v, p, dout, temperature, o=None):
+    dv = np.matmul(_rt(p).transpose(0, 2, 1), dout)
     dp = np.matmul(dout, v.transpose(0, 2, 1))
-    ds = p * (dp - (dp * p).sum(-1, keepdims=True)) / temperature
+    # bf16 storage: the row term comes from the stored (rounded) output, sum_j dO_j O_j, as a fused kernel has it
+    delta = (dout * o).sum(-1, keepdims=True) if (_bf16 and o is not None) else (dp * p).sum(-1, keepdims=True)
+    ds = _rt(p * (dp - delta) / temperature)
     dq = np.matmul(ds, k)
     dk = np.matmul(ds.transpose(0, 2, 1), q)
     return dq, dk, dv
@@ -111,65 +155,72 @@ def _merge_heads(x, n_head, B):
 def mha_fwd(w, pre, q_in, kv_in, mask, n_head, d_k, d_v):
     """lib/transformer/SubLayers.py:37-65 (eval mode).  mask bool (B,Lq,Lk)."""
     B = q_in.shape[0]
-    q = _split_heads(linear_fwd(q_in, w[pre + "w_qs.weight"], w[pre + "w_qs.bias"]), n_head, d_k)
-    k = _split_heads(linear_fwd(kv_in, w[pre + "w_ks.weight"], w[pre + "w_ks.bias"]), n_head, d_k)
-    v = _split_heads(linear_fwd(kv_in, w[pre + "w_vs.weight"], w[pre + "w_vs.bias"]), n_head, d_v)
+    q = _split_heads(_rt(linear_fwd(q_in, _wt(w, pre + "w_qs.weight"), w[pre + "w_qs.bias"])), n_head, d_k)
+    k = _split_heads(_rt(linear_fwd(kv_in, _wt(w, pre + "w_ks.weight"), w[pre + "w_ks.bias"])), n_head, d_k)
+    v = _split_heads(_rt(linear_fwd(kv_in, _wt(w, pre + "w_vs.weight"), w[pre + "w_vs.bias"])), n_head, d_v)
     mask_h = np.tile(mask, (n_head, 1, 1))  # SubLayers.py:54
     o, p = sdpa_fwd(q, k, v, mask_h, np.power(d_k, 0.5))
+    o = _rt(o)
     merged = _merge_heads(o, n_head, B)
-    fc = linear_fwd(merged, w[pre + "fc.weight"], w[pre + "fc.bias"])
+    fc = _rt(linear_fwd(merged, _wt(w, pre + "fc.weight"), w[pre + "fc.bias"]))
     out, ln_cache = layer_norm_fwd(fc + q_in, w[pre + "layer_norm.weight"], w[pre + "layer_norm.bias"])
-    cache = (q_in, kv_in, q, k, v, p, merged, ln_cache)
-    return out, p, cache
+    cache = (q_in, kv_in, q, k, v, p, merged, ln_cache, o)
+    return _rt(out), p, cache
 
 
 def mha_bwd(w, pre, dout, cache, n_head, d_k, d_v, grads):
-    q_in, kv_in, q, k, v, p, merged, ln_cache = cache
+    q_in, kv_in, q, k, v, p, merged, ln_cache, o = cache
     B = q_in.shape[0]
     dz, dg, db = layer_norm_bwd(dout, w[pre + "layer_norm.weight"], ln_cache)
     _acc(grads, pre + "layer_norm.weight", dg)
     _acc(grads, pre + "layer_norm.bias", db)
-    dmerged, dw, dbias = linear_bwd(merged, w[pre + "fc.weight"], dz)
+    _acc(grads, pre + "fc.bias", dz.reshape(-1, dz.shape[-1]).sum(0))  # summed before dz is stored
+    dz = _rt(dz)
+    dmerged, dw, _ = linear_bwd(merged, _wt(w, pre + "fc.weight"), dz, has_bias=False)
     _acc(grads, pre + "fc.weight", dw)
-    _acc(grads, pre + "fc.bias", dbias)
-    do = _split_heads(dmerged, n_head, d_v)
-    dq, dk, dv = sdpa_bwd(q, k, v, p, do, np.power(d_k, 0.5))
-    dq, dk, dv = _merge_heads(dq, n_head, B), _merge_heads(dk, n_head, B), _merge_heads(dv, n_head, B)
-    dq_in, dw, dbias = linear_bwd(q_in, w[pre + "w_qs.weight"], dq)
+    do = _split_heads(_rt(dmerged), n_head, d_v)
+    dq, dk, dv = sdpa_bwd(q, k, v, p, do, np.power(d_k, 0.5), o)
+    dq, dk, dv = (_rt(_merge_heads(g, n_head, B)) for g in (dq, dk, dv))
+    dq_in, dw, dbias = linear_bwd(q_in, _wt(w, pre + "w_qs.weight"), dq)
     _acc(grads, pre + "w_qs.weight", dw)
     _acc(grads, pre + "w_qs.bias", dbias)
-    dk_in, dw, dbias = linear_bwd(kv_in, w[pre + "w_ks.weight"], dk)
+    dk_in, dw, dbias = linear_bwd(kv_in, _wt(w, pre + "w_ks.weight"), dk)
     _acc(grads, pre + "w_ks.weight", dw)
     _acc(grads, pre + "w_ks.bias", dbias)
-    dv_in, dw, dbias = linear_bwd(kv_in, w[pre + "w_vs.weight"], dv)
+    dv_in, dw, dbias = linear_bwd(kv_in, _wt(w, pre + "w_vs.weight"), dv)
     _acc(grads, pre + "w_vs.weight", dw)
     _acc(grads, pre + "w_vs.bias", dbias)
-    return dq_in + dz, dk_in + dv_in  # residual = q_in (SubLayers.py:44,63)
+    # residual = q_in (SubLayers.py:44,63).  bf16 storage: the input gradient of the stacked projections and the
+    # residual branch are summed in fp32 and stored once (self-attention: all three projections share the input)
+    if _bf16 and kv_in is q_in:
+        return _rt(dq_in + dk_in + dv_in + dz), 0
+    return _rt(dq_in + dz), _rt(dk_in + dv_in)
 
 
 def ffn_fwd(w, pre, x):
     """lib/transformer/SubLayers.py:78-85 — Conv1d(k=1) weights are (out,in,1)."""
-    w1, w2 = w[pre + "w_1.weight"][:, :, 0], w[pre + "w_2.weight"][:, :, 0]
-    h = np.maximum(linear_fwd(x, w1, w[pre + "w_1.bias"]), 0)
-    y = linear_fwd(h, w2, w[pre + "w_2.bias"])
+    w1, w2 = _wt(w, pre + "w_1.weight")[:, :, 0], _wt(w, pre + "w_2.weight")[:, :, 0]
+    h = _rt(np.maximum(linear_fwd(x, w1, w[pre + "w_1.bias"]), 0))
+    y = _rt(linear_fwd(h, w2, w[pre + "w_2.bias"]))
     out, ln_cache = layer_norm_fwd(y + x, w[pre + "layer_norm.weight"], w[pre + "layer_norm.bias"])
-    return out, (x, h, ln_cache)
+    return _rt(out), (x, h, ln_cache)
 
 
 def ffn_bwd(w, pre, dout, cache, grads):
     x, h, ln_cache = cache
-    w1, w2 = w[pre + "w_1.weight"][:, :, 0], w[pre + "w_2.weight"][:, :, 0]
+    w1, w2 = _wt(w, pre + "w_1.weight")[:, :, 0], _wt(w, pre + "w_2.weight")[:, :, 0]
     dz, dg, db = layer_norm_bwd(dout, w[pre + "layer_norm.weight"], ln_cache)
     _acc(grads, pre + "layer_norm.weight", dg)
     _acc(grads, pre + "layer_norm.bias", db)
-    dh, dw2, db2 = linear_bwd(h, w2, dz)
+    _acc(grads, pre + "w_2.bias", dz.reshape(-1, dz.shape[-1]).sum(0))  # summed before dz is stored
+    dz = _rt(dz)
+    dh, dw2, _ = linear_bwd(h, w2, dz, has_bias=False)
     _acc(grads, pre + "w_2.weight", dw2[:, :, None])
-    _acc(grads, pre + "w_2.bias", db2)
-    dh = dh * (h > 0)
+    dh = _rt(dh * (h > 0))
     dx, dw1, db1 = linear_bwd(x, w1, dh)
     _acc(grads, pre + "w_1.weight", dw1[:, :, None])
     _acc(grads, pre + "w_1.bias", db1)
-    return dx + dz
+    return _rt(dx + dz)
 
 
 def _acc(grads, key, val):
@@ -250,7 +301,7 @@ def cast_weights(w, dtype):
 def encoder_fwd(w, cfg, src_seq, src_pos):
     """lib/transformer/Models.py:108-129."""
     keypad = src_seq == PAD
-    x = w["encoder.src_word_emb.weight"][src_seq] + w["encoder.position_enc.weight"][src_pos]
+    x = _rt(w["encoder.src_word_emb.weight"][src_seq] + w["encoder.position_enc.weight"][src_pos])
     caches, attns = [], []
     for i in range(cfg.n_layers):
         x, p, c = enc_layer_fwd(w, f"encoder.layer_stack.{i}.", x, keypad, cfg.attn)
@@ -277,7 +328,7 @@ def _embed_bwd(grads, key, shape, seq, dx):
 def decoder_fwd(w, cfg, tgt_seq, tgt_pos, src_seq, enc_out):
     """lib/transformer/Models.py:167-199."""
     keypad, src_keypad = tgt_seq == PAD, src_seq == PAD
-    x = w["decoder.tgt_word_emb.weight"][tgt_seq] + w["decoder.position_enc.weight"][tgt_pos]
+    x = _rt(w["decoder.tgt_word_emb.weight"][tgt_seq] + w["decoder.position_enc.weight"][tgt_pos])
     caches, a1s, a2s = [], [], []
     for i in range(cfg.n_layers):
         x, p1, p2, c = dec_layer_fwd(w, f"decoder.layer_stack.{i}.", x, enc_out, keypad, src_keypad, cfg.attn)
@@ -291,7 +342,7 @@ def decoder_bwd(w, cfg, tgt_seq, dout, caches, grads):
     dmem = 0
     for i in reversed(range(cfg.n_layers)):
         dout, dm = dec_layer_bwd(w, f"decoder.layer_stack.{i}.", dout, caches[i], cfg.attn, grads)
-        dmem = dmem + dm
+        dmem = _rt(dmem + dm)  # autograd adds the layers' contributions as stored tensors
     _embed_bwd(grads, "decoder.tgt_word_emb.weight", w["decoder.tgt_word_emb.weight"].shape, tgt_seq, dout)
     return dmem
 
@@ -301,7 +352,7 @@ def transformer_fwd(w, cfg, src_seq, src_pos, tgt_seq, tgt_pos):
     tgt_seq, tgt_pos = tgt_seq[:, :-1], tgt_pos[:, :-1]
     enc_out, _, enc_caches = encoder_fwd(w, cfg, src_seq, src_pos)
     dec_out, _, _, dec_caches = decoder_fwd(w, cfg, tgt_seq, tgt_pos, src_seq, enc_out)
-    logits = (dec_out @ w["generator.weight"].T) * cfg.x_logit_scale
+    logits = _rt((dec_out @ _wt(w, "generator.weight").T) * cfg.x_logit_scale)
     return logits, (src_seq, tgt_seq, enc_caches, dec_caches, dec_out)
 
 
@@ -313,7 +364,7 @@ def transformer_bwd(w, cfg, dlogits, cache):
     dl = dlogits * cfg.x_logit_scale
     d2 = dl.reshape(-1, dl.shape[-1])
     _acc(grads, "generator.weight", d2.T @ dec_out.reshape(-1, dec_out.shape[-1]))
-    ddec = dl @ w["generator.weight"]
+    ddec = _rt(dl @ _wt(w, "generator.weight"))
     dmem = decoder_bwd(w, cfg, tgt_seq, ddec, dec_caches, grads)
     encoder_bwd(w, cfg, src_seq, dmem, enc_caches, grads)
     return grads
@@ -353,7 +404,7 @@ def ls_xent(pred, gold, smoothing, eps=0.1):
     loss = row[non_pad].sum()
     dpred = (np.exp(logp) * q.sum(1, keepdims=True) - q) * non_pad[:, None]
     n_correct = int(((pred.argmax(1) == gold) & non_pad).sum())
-    return loss, dpred.astype(pred.dtype), n_correct
+    return loss, _rt(dpred.astype(pred.dtype)), n_correct  # a bf16 path stores the gradient in the logits' format
 
 
 # ----------------------------------------------------------------------------- optimiser

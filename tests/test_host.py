@@ -236,3 +236,14 @@ def test_token_budget_sampler_covers_every_sentence_once_within_budget():
     loader = torch.utils.data.DataLoader(ds, batch_sampler=sm2, collate_fn=paired_collate_fn)
     s_seq, s_pos, t_seq, t_pos = next(iter(loader))
     assert s_seq.shape == s_pos.shape and t_seq.shape[0] == s_seq.shape[0] <= 64
+
+
+def test_product_sinusoid_table_matches_reference_fixture():
+    """get_sinusoid_encoding_table of the drop-in package (lib/transformer/Models.py:26-46) against the tables the
+    reference's function produced (tests/golden/sinusoid.npz), bit for bit."""
+    from conftest import load_golden
+    from specialk_amd.lib.transformer.Models import get_sinusoid_encoding_table
+    g = load_golden("sinusoid")
+    np.testing.assert_array_equal(get_sinusoid_encoding_table(20, 32, padding_idx=0).numpy(), g["t_20_32"])
+    np.testing.assert_array_equal(get_sinusoid_encoding_table(7, 6, padding_idx=0).numpy(), g["t_7_6"])
+    np.testing.assert_array_equal(get_sinusoid_encoding_table(5, 8).numpy(), g["t_5_8_nopad"])

@@ -265,7 +265,7 @@ def oracle_attn(q, k, v, keypad, causal, dense=None):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("case", ["self_pad", "causal", "cross", "long", "dense", "d128"])
+@pytest.mark.parametrize("case", ["self_pad", "causal", "cross", "long", "dense", "d128", "h16_causal", "h16_cross"])
 def test_attention(L, dtype, case):
     g = torch.Generator().manual_seed(sum(map(ord, case)))
     B, H, Lq, Lk, dk, dv, causal, dense = {
@@ -275,6 +275,8 @@ def test_attention(L, dtype, case):
         "long": (1, 2, 150, 200, 64, 64, False, False),
         "dense": (2, 2, 9, 11, 16, 24, False, True),
         "d128": (2, 2, 20, 33, 128, 128, False, False),
+        "h16_causal": (3, 16, 52, 52, 64, 64, True, False),   # the Transformer-big head count (d = 16 x 64)
+        "h16_cross": (3, 16, 41, 52, 64, 64, False, False),
     }[case]
     q, k, v = rnd((B, Lq, H, dk), dtype, g), rnd((B, Lk, H, dk), dtype, g), rnd((B, Lk, H, dv), dtype, g)
     lens = torch.randint(max(1, Lk // 2), Lk + 1, (B,), generator=g)

@@ -163,6 +163,30 @@ def test_train4():
         close(w[k], w4[k], rtol=2e-4)
 
 
+def test_deep_train30():
+    """Thirty optimiser steps of a 6 + 6 layer stack on a copy task against the reference's trajectory: the loss
+    follows it step by step, and (like the reference) stays on the unigram plateau — accuracy near the share of
+    EOS targets — for the whole run.  Tolerance widens with the step: every update feeds fp32 rounding
+    differences back through Adam."""
+    g = load_golden("deep_train30")
+    w = {k: v.copy() for k, v in split_prefixed(g, "w0:").items()}
+    cfg = O.Config(6, 4, 8, 8, 32, 64)
+    trainable = [k for k in w if "position_enc" not in k]
+    m = {k: np.zeros_like(w[k]) for k in trainable}
+    v = {k: np.zeros_like(w[k]) for k in trainable}
+    for step in range(30):
+        seq, pos = g[f"seq_{step}"], g[f"pos_{step}"]
+        logits, cache = O.transformer_fwd(w, cfg, seq, pos, seq, pos)
+        loss, dpred, nc = O.ls_xent(logits.reshape(-1, logits.shape[-1]), seq[:, 1:].reshape(-1), True)
+        assert abs(loss - g["losses"][step]) <= (2e-5 + 2e-5 * step) * abs(g["losses"][step]), step
+        assert abs(nc - g["ncorrect"][step]) <= (0 if step < 5 else 2), step
+        grads = O.transformer_bwd(w, cfg, dpred.reshape(logits.shape), cache)
+        lr = np.float32(O.noam_lr(step + 1, cfg.d_model, int(g["n_warmup"])))
+        for k in trainable:
+            O.adam_step(w[k], grads[k], m[k], v[k], step + 1, lr)
+    assert (g["ncorrect"][5:] / g["nwords"][5:]).max() < 0.2  # the reference does not get off the plateau either
+
+
 def test_beam():
     g = load_golden("beam")
     w = split_prefixed(g, "w:")

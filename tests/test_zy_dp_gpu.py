@@ -25,7 +25,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, out, packed, bf16=False, backend="gloo"):
+def _worker(rank, world, port, out, packed, bf16=False, backend="gloo", tied=False):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import faulthandler
@@ -39,8 +39,8 @@ def _worker(rank, world, port, out, packed, bf16=False, backend="gloo"):
     torch.cuda.set_device(0)
     extra = {"device_id": torch.device("cuda", 0)} if backend == "nccl" else {}
     dist.init_process_group(backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=90), **extra)
-    g = load_golden("transformer_untied")
-    m = load_sd(build_tiny(g, False), split_prefixed(g, "w:")).eval()
+    g = load_golden("transformer_tied" if tied else "transformer_untied")
+    m = load_sd(build_tiny(g, tied), split_prefixed(g, "w:")).eval()
     if bf16:
         m = m.set_compute_dtype(torch.bfloat16)
     params = [p for p in m.parameters() if p.requires_grad]
@@ -70,7 +70,7 @@ def _worker(rank, world, port, out, packed, bf16=False, backend="gloo"):
     if rank == 0:
         res = {"grads": {k: p.grad.cpu() for k, p in m.named_parameters() if p.grad is not None}, "stats": tot.cpu()}
         if bf16:  # reference for the bf16 run: the same arithmetic on the whole batch in one process, through autograd
-            m2 = load_sd(build_tiny(g, False), split_prefixed(g, "w:")).eval().set_compute_dtype(torch.bfloat16)
+            m2 = load_sd(build_tiny(g, tied), split_prefixed(g, "w:")).eval().set_compute_dtype(torch.bfloat16)
             logits, gold = m2.forward_packed(*batch) if packed else (None, None)
             if not packed:
                 logits = m2(*batch)
@@ -83,13 +83,17 @@ def _worker(rank, world, port, out, packed, bf16=False, backend="gloo"):
     dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("tied", [False, True])
 @pytest.mark.parametrize("packed", [True, False])
-def test_two_rank_step_matches_full_batch_gradients(tmp_path, packed):
+def test_two_rank_step_matches_full_batch_gradients(tmp_path, packed, tied):
+    """tied: one matrix is source embedding, target embedding and generator (the Transformer-big setting); its
+    gradient has three producers per rank and lives once in the reducer's buckets."""
     out = str(tmp_path / "dp.pt")
     # ranks are forked from the clean fork server started in conftest.py (see there)
-    mp.start_processes(_worker, args=(2, _free_port(), out, packed), nprocs=2, join=True, start_method="forkserver")
+    mp.start_processes(_worker, args=(2, _free_port(), out, packed, False, "gloo", tied), nprocs=2, join=True,
+                       start_method="forkserver")
     got = torch.load(out)
-    g = load_golden("transformer_untied")
+    g = load_golden("transformer_tied" if tied else "transformer_untied")
     assert abs(float(got["stats"][0]) - float(g["loss_ls"])) <= 1e-5 * float(g["loss_ls"])
     assert int(got["stats"][1]) == int(g["ncorrect_ls"])
     for k, ref in split_prefixed(g, "g_ls:").items():
@@ -97,12 +101,14 @@ def test_two_rank_step_matches_full_batch_gradients(tmp_path, packed):
         assert np.abs(a - b).max() <= 1e-5 * np.abs(b).max() + 2e-6, k
 
 
+@pytest.mark.parametrize("tied", [False, True])
 @pytest.mark.parametrize("packed", [True, False])
-def test_two_rank_step_bf16_grouped_weight_grads(tmp_path, packed):
+def test_two_rank_step_bf16_grouped_weight_grads(tmp_path, packed, tied):
     """bf16 with the grouped weight-gradient launches accumulating into the reducer's bucket views:
     the two ranks' summed gradients against a one-process whole-batch run of the same arithmetic."""
     out = str(tmp_path / "dp.pt")
-    mp.start_processes(_worker, args=(2, _free_port(), out, packed, True), nprocs=2, join=True, start_method="forkserver")
+    mp.start_processes(_worker, args=(2, _free_port(), out, packed, True, "gloo", tied), nprocs=2, join=True,
+                       start_method="forkserver")
     got = torch.load(out)
     assert got["grads"].keys() == got["ref"].keys()
     for k, ref in got["ref"].items():

@@ -377,6 +377,41 @@ def gen_train3():
     save("train4", **arrs)
 
 
+def gen_deep_train30():
+    """A deep (6 + 6 layer) post-LN stack through 30 optimiser steps of a copy task (target = source), the
+    configuration the trainer is benchmarked in scaled down to d = 32: per-step loss, accuracy and token counts
+    from the reference's own modules, initial weights and every batch.  Eval-mode dropout as in train4."""
+    torch.manual_seed(61)
+    g = torch.Generator().manual_seed(62)
+    vocab = 40
+    cfg = dict(TINY)
+    cfg.update(n_layers=6, len_max_seq=14)
+    m = Transformer(vocab, vocab, tgt_emb_prj_weight_sharing=False, emb_src_tgt_weight_sharing=False, **cfg)
+    xavier_like_initiate(m)
+    m.eval()
+    n_warm = 10
+    so = ScheduledOptim(optim.Adam(filter(lambda x: x.requires_grad, m.parameters()), betas=(0.9, 0.98), eps=1e-09),
+                        cfg["d_model"], n_warm)
+    arrs = {"vocab": np.array([vocab, vocab], dtype=np.int64), "n_warmup": np.int64(n_warm), "n_layers": np.int64(6),
+            "len_max_seq": np.int64(14)}
+    arrs.update(sd_arrays("w0:", m))
+    losses, ncs, nws = [], [], []
+    for step in range(30):
+        seq, pos = make_batch(g, 16, 3, 10, vocab)
+        so.zero_grad()
+        pred = m(seq, pos, seq, pos)
+        gold = seq[:, 1:]
+        loss, nc = performance(pred.view(-1, pred.size(2)), gold, True)
+        loss.backward()
+        so.step_and_update_lr()
+        losses.append(loss.item()); ncs.append(nc); nws.append(gold.ne(PAD).sum().item())
+        arrs.update({f"seq_{step}": npy(seq), f"pos_{step}": npy(pos)})
+    arrs["losses"] = np.array(losses, dtype=np.float64)
+    arrs["ncorrect"] = np.array(ncs, dtype=np.int64)
+    arrs["nwords"] = np.array(nws, dtype=np.int64)
+    save("deep_train30", **arrs)
+
+
 def gen_beam():
     """Copy-task model with healthy top-k margins, then the reference beam search on it."""
     torch.manual_seed(61)
@@ -512,5 +547,6 @@ if __name__ == "__main__":
     gen_loss()
     gen_optim()
     gen_train3()
+    gen_deep_train30()
     gen_beam()
     gen_cfg1_checksum()
