@@ -150,11 +150,11 @@ def gemm_roofline(m, opt, batch, steps):
     # HBM-side bytes per GEMM launch from the committed counter passes of this same command (rocprofv3 --pmc
     # FETCH_SIZE and --pmc WRITE_SIZE, separate runs; tools/pmc_hbm_traffic.py): counters cannot be read in-process
     traffic, traffic_src = None, None
-    pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_hbm_traffic.json")
+    pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_hbm_traffic.json")
     if os.path.exists(pmc):
         with open(pmc) as f:
             traffic = round(json.load(f)["hbm_bytes_per_launch"])
-        traffic_src = "profiles/r01_pmc_hbm_traffic.json (bytes per launch, cfg2)"
+        traffic_src = "profiles/r02_pmc_hbm_traffic.json (bytes per launch, cfg2)"
     out = _roofline_dict(flops, ms, n, steps)
     out["traffic"], out["traffic_source"] = traffic, traffic_src
     return out
@@ -198,7 +198,7 @@ def cpu_baseline(cfg, seconds_budget=25.0):
             w[pre + "pos_ffn.layer_norm.weight"] = np.ones(d, np.float32); w[pre + "pos_ffn.layer_norm.bias"] = np.zeros(d, np.float32)
     ocfg = O.Config(NL, H, dk, dk, d, F)
     g = torch.Generator().manual_seed(7)
-    n_sent = 8
+    n_sent = 64
     src_seq, src_pos = (x.numpy() for x in make_batch(g, n_sent, cfg["lo"], cfg["hi"], V))
     tgt_seq, tgt_pos = (x.numpy() for x in make_batch(g, n_sent, cfg["lo"], cfg["hi"], V))
     trainable = [k for k in w if "position_enc" not in k]
@@ -216,7 +216,7 @@ def cpu_baseline(cfg, seconds_budget=25.0):
     with (threadpool_limits(limits=cores) if threadpool_limits else contextlib.nullcontext()):
         step(1)  # warm-up
         t0, n = time.time(), 0
-        while time.time() - t0 < seconds_budget and n < 20:
+        while n < 2 or (time.time() - t0 < seconds_budget and n < 20):
             step(n + 2)
             n += 1
         dt = time.time() - t0
@@ -270,11 +270,17 @@ def decode_leg(device, n_batches=10, batch=128, beam=5, max_len=150, copy_task_s
     m, _ = build(cfg, torch.bfloat16, device)
     m.eval()
     sent, tok, exact, dt, nbytes = run(m, cfg["vocab"], n_batches)
+    traffic, traffic_src = None, None  # counter passes of this same leg, committed (counters cannot be read in-process)
+    pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_decode_hbm_traffic.json")
+    if os.path.exists(pmc) and (batch, beam, max_len) == (128, 5, 150):
+        with open(pmc) as f:
+            traffic = round(json.load(f)["hbm_bytes_per_step"])
+        traffic_src = "profiles/r02_pmc_decode_hbm_traffic.json (bytes per step)"
     out["worst_case"] = dict(model="6+6 d512 FFN2048 V35000, random weights (no EOS: all 150 steps, 640 beams alive)",
                              sentences=sent, sentences_per_sec=round(sent / dt, 1), tokens_per_sec=round(tok / dt, 1),
                              mean_output_length=round(tok / sent, 1), ms_per_step=round(dt / (n_batches * max_len) * 1e3, 4),
                              roofline=dict(bound="hbm", achieved=round(nbytes / dt / 1e9, 1), peak=8000.0, unit="GB/s",
-                                           frac=round(nbytes / dt / 8e12, 4), traffic=None,
+                                           frac=round(nbytes / dt / 8e12, 4), traffic=traffic, traffic_source=traffic_src,
                                            algorithmic_bytes_per_step=round(nbytes / (n_batches * max_len))))
     del m
     if copy_task_steps:
@@ -323,6 +329,8 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--padded", action="store_true", help="keep padding rows (the reference's tensor shapes)")
     ap.add_argument("--no-decode", action="store_true", help="skip the beam-decode leg")
+    ap.add_argument("--decode-only", action="store_true",
+                    help="profiling aid: run only the beam-decode leg (worst case, 3 batches) and print its result")
     args = ap.parse_args()
 
     # stdout carries exactly one line, the result: libraries that write to file descriptor 1 themselves (RCCL
@@ -349,6 +357,10 @@ def main():
         backend = os.environ.get("SK_BENCH_BACKEND", "nccl")  # "gloo": rehearsal of the N > 1 flow on one card
         dist.init_process_group(backend, rank=rank, world_size=world, **({"device_id": device} if backend == "nccl" else {}))
 
+    if args.decode_only:
+        out = decode_leg(device, n_batches=3, copy_task_steps=0)
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
+        return
     cfg = CONFIGS[args.config]
     global PACKED
     PACKED = not args.padded
