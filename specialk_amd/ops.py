@@ -292,13 +292,35 @@ def batched_weight_grads(on_ready=None, flush_tiles=256):
         _wgrad_batch = None
 
 
+def _reducer():
+    """The data-parallel reducer whose mark_ready the current batched_weight_grads() context reports to, if it
+    hands out its bucket slices (claim), else None."""
+    b = _wgrad_batch
+    r = getattr(b.on_ready, "__self__", None) if b is not None and b.on_ready is not None else None
+    return r if r is not None and hasattr(r, "claim") else None
+
+
+def _claim_grad(p):
+    """(bucket slice to write the gradient of p into, accumulate?) inside a batched_weight_grads() context that
+    reports to a reducer; (None, False) otherwise.  For producers whose result reaches .grad through autograd: the
+    first producer of the step overwrites the slice and returns a fresh alias of it (autograd adopts it, so .grad
+    IS the slice); a later producer of the same matrix adds to the slice in place and returns None."""
+    r = _reducer()
+    return r.claim(p) if r is not None and p.grad is None else (None, False)
+
+
 def _grad_target(p, fixups, reducer=None):
     """(tensor the launch writes, accumulate?) for the gradient of p: p.grad itself when it can be written in
-    place, a fresh tensor that becomes p.grad when there is none, else a temporary that is added afterwards."""
+    place, the reducer's bucket slice or a fresh tensor that becomes p.grad when there is none, else a temporary
+    that is added afterwards."""
     g = p.grad
     if g is None:
-        view = reducer.bucket_view(p) if reducer is not None and hasattr(reducer, "bucket_view") else None
-        g = p.grad = view if view is not None else torch.empty(p.shape, dtype=torch.float32, device=p.device)
+        view, acc = reducer.claim(p) if reducer is not None else (None, False)
+        if view is not None:
+            if not acc:  # (acc: an alias of the slice is already on its way to .grad through autograd)
+                p.grad = view
+            return view, acc
+        g = p.grad = torch.empty(p.shape, dtype=torch.float32, device=p.device)
         return g, False
     if g.dtype == torch.float32 and g.is_contiguous():
         return g, True
@@ -313,10 +335,10 @@ def _flush_weight_grads():
         return
     items, b.items, b.tiles, b.seen = b.items, [], 0, set()
     problems, fixups, params = [], [], []
-    reducer = getattr(b.on_ready, "__self__", None) if b.on_ready is not None else None
+    reducer = _reducer()
     with torch.no_grad():
         for dy, x, W, n, d_in, T, bias in items:
-            out, acc = _grad_target(W, fixups)
+            out, acc = _grad_target(W, fixups, reducer)
             cs, cs_acc = (None, False) if bias is None else _grad_target(bias, fixups, reducer)
             problems.append((dy, x, out, n, d_in, T, dy.stride(0), x.stride(0), d_in, acc, cs, cs_acc))
             params.append(W)
@@ -390,8 +412,14 @@ class LinearFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = _input_grad(dy, N, (W,), T, K, x.dtype, alpha=ctx.alpha)
         if ctx.needs_input_grad[1]:
-            dW = L.gemm(L.GEMM_TN, dy, x, N, K, T, N, x.stride(0), alpha=ctx.alpha, out_dtype=torch.float32)
-            dW = dW.view(W.shape)
+            view, acc = _claim_grad(W)
+            if view is not None:
+                L.gemm(L.GEMM_TN, dy, x, N, K, T, N, x.stride(0), out=view.view(N, K), ldc=K, alpha=ctx.alpha,
+                       epilogue=L.EPI_ACCUM if acc else 0)
+                dW = None if acc else view.view(W.shape)
+            else:
+                dW = L.gemm(L.GEMM_TN, dy, x, N, K, T, N, x.stride(0), alpha=ctx.alpha, out_dtype=torch.float32)
+                dW = dW.view(W.shape)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = L.colsum(dy, T, N, N)
         return dx, dW, db, None
@@ -635,13 +663,19 @@ class EmbedFn(torch.autograd.Function):
         seq, pos = seq.contiguous().view(-1), pos.contiguous().view(-1)
         out = L.embed_fwd(seq, pos, word_emb.detach(), pos_table.detach(), dtype)
         ctx.save_for_backward(seq)
-        ctx.shape = word_emb.shape
+        ctx.shape, ctx.table = word_emb.shape, word_emb
         return out
 
     @staticmethod
     def backward(ctx, dout):
         (seq,) = ctx.saved_tensors
         _check_residual_handoff()
+        view, acc = _claim_grad(ctx.table) if ctx.needs_input_grad[2] else (None, False)
+        if view is not None:
+            if not acc:
+                view.zero_()
+            L.embed_bwd(seq, dout.contiguous(), view, PAD)
+            return None, None, (None if acc else view.view(ctx.shape)), None, None
         dW = torch.zeros(ctx.shape, dtype=torch.float32, device=dout.device)
         L.embed_bwd(seq, dout.contiguous(), dW, PAD)
         return None, None, dW, None, None

@@ -13,12 +13,16 @@ point-to-point (7 links x ~153 GB/s per GPU) and RCCL's ring moves 2(N-1)/N of t
 one link pair per step, so buckets must be large enough (tens of MB) to reach link bandwidth
 yet small enough that the last bucket's exposed tail stays short.
 
-One-dimensional parameters (biases, LayerNorm gains and offsets: 156 of them in a 6+6 Transformer) are
-handled differently from matrices: while a bucket view is attached as .grad, autograd ADDS every new
-gradient into it with a kernel of its own (~5 us each, 0.8 ms per step).  Their .grad is therefore left
-empty during backward — autograd then adopts the freshly computed tensor without a kernel — and when
-their bucket is complete all of them are copied into it by one multi-tensor copy, after which .grad is
-the bucket view again.
+While gradients are being exchanged, no parameter carries a .grad at the start of a step and the buckets are
+NOT zeroed (392 MB per step for the base model): the first producer of a gradient overwrites its slice.
+  * The grouped weight-gradient launches and the embedding / generator products ask `claim(p)` for the slice
+    and write it in place (first producer of the step: overwrite; later producers of a shared matrix — tied
+    embeddings and generator — accumulate into it).
+  * Everything else reaches .grad through autograd, which adopts the freshly computed tensor without a kernel
+    when .grad is empty (with a bucket view attached it would ADD into it with a kernel per tensor: 156
+    one-dimensional parameters in a 6+6 Transformer, ~5 us each).  When a bucket is complete those tensors are
+    copied into it by one multi-tensor copy, after which .grad is the bucket view again.
+  * A parameter that got no gradient in a step has its slice zeroed in finish(), before the bucket is reduced.
 """
 import torch
 import torch.distributed as dist
@@ -57,6 +61,13 @@ class GradBucketReducer:
         self._staged = (self.active and self.buckets and self.buckets[0][0].is_cuda
                         and dist.get_backend(process_group) != "nccl")
         self._bucket_of = {p.data_ptr(): bi for bi, (_, plist) in enumerate(self.buckets) for p in plist}
+        self._views, self._claimed = {}, set()
+        self.gathered_matrix_bytes = 0  # diagnostics: matrix gradients that took the copy instead of a direct write
+        for flat, plist in self.buckets:
+            off = 0
+            for p in plist:
+                self._views[id(p)] = flat[off:off + p.numel()].view(p.shape)
+                off += p.numel()
         if self.active and not self._staged:
             for bi, (_, plist) in enumerate(self.buckets):
                 for p in plist:
@@ -68,27 +79,23 @@ class GradBucketReducer:
         self.buckets.append((flat, list(plist)))
         self._reattach(flat, plist)
 
-    @staticmethod
-    def _late(p):
-        """Gradients that autograd produces as small tensors of their own (see the module docstring)."""
-        return p.dim() == 1
-
     def _gather_late(self, bi):
-        """Copy the adopted gradients of the bucket's one-dimensional parameters into the bucket."""
+        """Copy the gradients that autograd adopted as tensors of their own into the bucket."""
         flat, plist = self.buckets[bi]
         views, grads, off = [], [], 0
         for p in plist:
             n = p.numel()
-            if self._late(p) and p.grad is not None and p.grad.data_ptr() != flat.data_ptr() + 4 * off:
+            if p.grad is not None and p.grad.data_ptr() != flat.data_ptr() + 4 * off:
                 views.append(flat[off:off + n].view(p.shape))
                 grads.append(p.grad)
+                self.gathered_matrix_bytes += 4 * n * (p.dim() > 1)
             off += n
         if views:
             torch._foreach_copy_(views, grads)
             off = 0
             for p in plist:
                 n = p.numel()
-                if self._late(p) and p.grad is not None:
+                if p.grad is not None:
                     p.grad = flat[off:off + n].view(p.shape)
                 off += n
 
@@ -103,17 +110,22 @@ class GradBucketReducer:
 
     def bucket_view(self, p):
         """The slice of its bucket that holds the gradient of p, for producers that write a gradient in place
-        (ops.batched_weight_grads writes bias gradients there and then calls mark_ready); None when gradients
+        (ops.batched_weight_grads writes gradients there and then calls mark_ready); None when gradients
         are staged through host copies or nothing is reduced (the caller then allocates a tensor of its own)."""
         if not self.active or self._staged:
             return None
-        flat, plist = self.buckets[self._bucket_of[p.data_ptr()]]
-        off = 0
-        for q in plist:
-            if q is p:
-                return flat[off:off + p.numel()].view(p.shape)
-            off += q.numel()
-        return None
+        return self._views.get(id(p))
+
+    def claim(self, p):
+        """(slice of the bucket that holds the gradient of p, accumulate?) for a producer that writes in place:
+        the first claim of a step must overwrite the slice (it still holds the previous step's sum), later ones
+        — further uses of a shared matrix — add to it.  (None, False) when there is nothing to write into."""
+        view = self.bucket_view(p)
+        if view is None:
+            return None, False
+        first = id(p) not in self._claimed
+        self._claimed.add(id(p))
+        return view, not first
 
     def mark_ready(self, params):
         """Cue for gradients that were written into the bucket views directly instead of being
@@ -123,21 +135,33 @@ class GradBucketReducer:
                 self._make_hook(self._bucket_of[p.data_ptr()])(p)
 
     def zero_grad(self):
-        """Zero the flat buckets in place (gradient views stay attached to the parameters)."""
+        """Start a step.  Exchanging gradients: every .grad is dropped and nothing is zeroed (see the module
+        docstring).  Otherwise (one rank, nothing to reduce): the buckets are zeroed in place and stay attached as
+        the parameters' .grad."""
         for bi, (flat, plist) in enumerate(self.buckets):
-            flat.zero_()
+            if not self.active:
+                flat.zero_()
             self._pending[bi] = len(plist)
             self._reattach(flat, plist)  # also repairs views a foreign zero_grad(set_to_none=True) detached
+        self._claimed = set()
         self._handles = []
 
     def _reattach(self, flat, plist):
-        """Matrices get their bucket view as .grad; one-dimensional parameters start the step without one."""
         off = 0
         for p in plist:
-            if self._late(p) and self.active:
+            if self.active:
                 p.grad = None
             elif p.grad is None or p.grad.data_ptr() != flat.data_ptr() + 4 * off:
                 p.grad = flat[off:off + p.numel()].view(p.shape)
+            off += p.numel()
+
+    def _zero_missing(self, bi):
+        """Parameters without a gradient this step (unused ones) contribute zeros to the sum."""
+        flat, plist = self.buckets[bi]
+        off = 0
+        for p in plist:
+            if p.grad is None and id(p) not in self._claimed:
+                flat[off:off + p.numel()].zero_()
             off += p.numel()
 
     def finish(self):
@@ -145,6 +169,7 @@ class GradBucketReducer:
         step (unused parameters) are reduced here so that all ranks stay in lock-step."""
         if self._staged:
             for bi, (flat, _) in enumerate(self.buckets):
+                self._zero_missing(bi)
                 self._gather_late(bi)
                 host = flat.cpu()
                 dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
@@ -153,12 +178,13 @@ class GradBucketReducer:
         elif self.active:
             for bi, (flat, _) in enumerate(self.buckets):
                 if self._pending[bi] > 0:
+                    self._zero_missing(bi)
                     self._gather_late(bi)
                     self._handles.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
                     self._pending[bi] = 0
             for h in self._handles:
                 h.wait()
-        if self.active:  # one-dimensional parameters that got no gradient this step read as zero, like the rest
+        if self.active:  # every .grad is the bucket view again (parameters without a gradient read as zero)
             for flat, plist in self.buckets:
                 off = 0
                 for p in plist:

@@ -127,8 +127,9 @@ def _dp_worker(rank, world, port, out):
     direct = []
 
     class DirectGradLinear(torch.autograd.Function):
-        """A layer that, like ops.batched_weight_grads, writes its weight gradient into .grad itself
-        and hands autograd None for it: the reducer learns about it through mark_ready()."""
+        """A layer that, like ops.batched_weight_grads, writes its weight gradient into the reducer's bucket
+        slice itself (claim: the first write of a step overwrites) and hands autograd None for it: the reducer
+        learns about it through mark_ready()."""
 
         @staticmethod
         def forward(ctx, inp, W, b):
@@ -138,7 +139,10 @@ def _dp_worker(rank, world, port, out):
         @staticmethod
         def backward(ctx, dy):
             inp, W = ctx.saved_tensors
-            W.grad.add_(dy.t() @ inp)
+            view, acc = red.claim(W)
+            assert not acc and W.grad is None
+            view.copy_(dy.t() @ inp)
+            W.grad = view
             direct.append(W)
             return dy @ W, None, dy.sum(0)
 

@@ -68,7 +68,8 @@ def _worker(rank, world, port, out, packed, bf16=False, backend="gloo", tied=Fal
     if world == 1:  # all_reduce_scalars has nothing to do for one rank: reduce a device tensor over the backend anyway
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
     if rank == 0:
-        res = {"grads": {k: p.grad.cpu() for k, p in m.named_parameters() if p.grad is not None}, "stats": tot.cpu()}
+        res = {"grads": {k: p.grad.cpu() for k, p in m.named_parameters() if p.grad is not None}, "stats": tot.cpu(),
+               "gathered_matrix_bytes": red.gathered_matrix_bytes}
         if bf16:  # reference for the bf16 run: the same arithmetic on the whole batch in one process, through autograd
             m2 = load_sd(build_tiny(g, tied), split_prefixed(g, "w:")).eval().set_compute_dtype(torch.bfloat16)
             logits, gold = m2.forward_packed(*batch) if packed else (None, None)
@@ -116,21 +117,26 @@ def test_two_rank_step_bf16_grouped_weight_grads(tmp_path, packed, tied):
         assert float((a - b).norm()) <= 3e-2 * float(b.norm()) + 1e-6, k
 
 
+@pytest.mark.parametrize("tied", [False, True])
 @pytest.mark.parametrize("bf16", [False, True])
-def test_one_rank_rccl_rehearsal(tmp_path, bf16):
+def test_one_rank_rccl_rehearsal(tmp_path, bf16, tied):
     """The RCCL form of the exchange on the one card there is: a group of one rank over the nccl backend with
     the reducer forced to reduce — hooks and grouped launches start asynchronous all-reduces of the device
     buckets on RCCL's stream during backward, finish() waits for them, scalars are reduced on the device.
-    A sum over one rank changes nothing, so the gradients must equal the whole-batch gradients."""
+    A sum over one rank changes nothing, so the gradients must equal the whole-batch gradients.  In the trainer's
+    form (bf16, grouped launches reporting to the reducer) every matrix gradient — the tied embedding / generator
+    matrix with its three producers included — is written straight into its bucket slice: none takes the copy."""
     out = str(tmp_path / "dp.pt")
-    mp.start_processes(_worker, args=(1, _free_port(), out, True, bf16, "nccl"), nprocs=1, join=True, start_method="forkserver")
+    mp.start_processes(_worker, args=(1, _free_port(), out, True, bf16, "nccl", tied), nprocs=1, join=True,
+                       start_method="forkserver")
     got = torch.load(out)
     if bf16:
+        assert got["gathered_matrix_bytes"] == 0
         for k, ref in got["ref"].items():
             a, b = got["grads"][k].double(), ref.double()
             assert float((a - b).norm()) <= 3e-2 * float(b.norm()) + 1e-6, k
     else:
-        g = load_golden("transformer_untied")
+        g = load_golden("transformer_tied" if tied else "transformer_untied")
         assert abs(float(got["stats"][0]) - float(g["loss_ls"])) <= 1e-5 * float(g["loss_ls"])
         for k, ref in split_prefixed(g, "g_ls:").items():
             a, b = got["grads"][k].double().numpy(), ref.astype(np.float64)
