@@ -297,8 +297,10 @@ int skhip_convert(const void* src, void* dst, int64_t n, int src_dtype, int dst_
  * (Translator.py:65-101 re-orders whole tensors); re-ordering this small table instead leaves
  * the caches in place.
  * new_k / new_v (optional, [R][ld_new] rows, heads at h*dk / h*dv): key and value of the newest
- * position len-1, taken from there and WRITTEN into the caches (row hist_row[r][len-1], or r) by
- * this call — the cache append of the k / v projections without launches of their own.        */
+ * position (kv_len[r]-1, or len-1 when kv_len is NULL), taken from there and WRITTEN into the caches
+ * (row hist_row[r][that position], or r) by this call — the cache append of the k / v projections
+ * without launches of their own.  With kv_len given, `len` is only the upper bound of the history
+ * (the launch then does not depend on the step number: a captured HIP graph can replay it).      */
 int skhip_decode_attn(const void* q, void* Kc, void* Vc, void* out,
                       const int32_t* kv_len, const uint8_t* key_pad, const int32_t* hist_row,
                       const void* new_k, const void* new_v, int64_t ld_new, int R, int n_head, int len,
