@@ -321,6 +321,32 @@ int skhip_beam_topk(const float* logits, const float* scores_in, float* scores_o
                     int32_t* prev_out, int32_t* tok_out, void* ws, int n_sent, int bm, int64_t V,
                     int first_step, int normalize, void* stream);
 
+/* One decode step of the WHOLE decoder stack in one launch (bf16; d_model 512, 8 heads of 64, d_inner 2048 — other
+ * shapes: SK_ERR_ARG, use the entry points above op by op).  Replaces, for the newest position of every beam row,
+ * Decoder.forward (lib/transformer/Models.py:173-196) as Translator.predict_word calls it once per step
+ * (lib/transformer/Translator.py:121-140): embedding, and per layer self-attention over the cached prefix
+ * (appending the new key / value to the caches), encoder-decoder attention, feed-forward, with their residuals and
+ * LayerNorms.  Teams of 8 workgroups own 32 rows each for the whole stack and exchange slices through the
+ * workspace; no other synchronisation, fixed summation orders.
+ * layers: HOST table, n_layers x 22 device addresses per layer (consumed during the call):
+ *   {Wqkv bf16 [1536][512] (rows q | k | v), bqkv f32 [1536], Wo bf16 [512][512], bo, ln1 gamma, ln1 beta,
+ *    Wq_enc bf16 [512][512], bq_enc, Wo_enc bf16 [512][512], bo_enc, ln2 gamma, ln2 beta,
+ *    W1 bf16 [2048][512], b1, W2 bf16 [512][2048], b2, ln3 gamma, ln3 beta,
+ *    Kcache, Vcache bf16 [R][Tc][512], encK, encV bf16 [n_sent][Ls][512]}   (all 16-byte aligned).
+ * tok, pos int64 [R]; cur_len int32 [R] (history length of row r including the new position); row_pad uint8 [R];
+ * pad_hist uint8 [R][Tc]; hist int32 [R][Tc] (history-row table as for skhip_decode_attn); src_key_pad uint8
+ * [n_sent][Ls]; dec_out bf16 [R][512].  R <= 32 x (CUs / 8) rows, sentence of row r = r / bm.
+ * workspace: skhip_decode_stack_ws_bytes(R) bytes, 256-byte aligned, whose first 1024 bytes the caller zeroes ONCE
+ * before the first call of a decode run; parity: 0 / 1, alternating from call to call (the launch of one parity
+ * resets the team counters of the other).  The first 1024 bytes end with an error word (int32 at byte 256): non-zero
+ * after a step means a team member stopped waiting for its team (results invalid).                               */
+int64_t skhip_decode_stack_ws_bytes(int R);
+int skhip_decode_stack(const int64_t* layers, int n_layers, const int64_t* tok, const int64_t* pos,
+                       const float* word_emb, const float* pos_tab, const int32_t* cur_len, const uint8_t* row_pad,
+                       const uint8_t* pad_hist, const int32_t* hist, const uint8_t* src_key_pad, void* dec_out,
+                       void* workspace, int64_t workspace_bytes, int R, int bm, int Tc, int Ls, int d_model, int n_head,
+                       int d_head, int d_inner, float scale, float eps, int parity, void* stream);
+
 /* The bookkeeping between two decoder steps of the beam search, for all sentences, in one launch:
  * Beam.advance's state update (lib/transformer/Beam.py:64-79: scores, prev_ks, next_ys, the EOS test on the
  * best beam), the active-sentence bookkeeping of Translator.py:142-168 and the next step's decoder inputs

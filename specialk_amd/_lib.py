@@ -23,6 +23,7 @@ EXPORTS = [
     "skhip_attn_bwd", "skhip_attn_varlen_fwd", "skhip_attn_varlen_bwd", "skhip_add_ln_fwd", "skhip_add_ln_bwd_ws_floats", "skhip_add_ln_bwd", "skhip_embed_fwd",
     "skhip_embed_bwd", "skhip_pack_plan", "skhip_xent_fwd_bwd", "skhip_adam_multi", "skhip_cast_multi", "skhip_cast2d_multi", "skhip_convert",
     "skhip_decode_attn", "skhip_beam_topk_ws_bytes", "skhip_beam_topk", "skhip_beam_update", "skhip_gather_rows",
+    "skhip_decode_stack_ws_bytes", "skhip_decode_stack",
     "skhip_softmax_rows", "skhip_conv_windows", "skhip_cnn_head", "skhip_collate",
 ]
 
@@ -73,6 +74,9 @@ def load():
     lib.skhip_decode_attn.argtypes = [c_p] * 9 + [c_i64] + [c_int] * 6 + [c_i64, c_i64, c_f32, c_int, c_int, c_p]
     lib.skhip_beam_topk.argtypes = [c_p] * 6 + [c_int, c_int, c_i64, c_int, c_int, c_p]
     lib.skhip_beam_update.argtypes = [c_p] * 16 + [c_int] * 6 + [c_p]
+    lib.skhip_decode_stack_ws_bytes.argtypes = [c_int]
+    lib.skhip_decode_stack_ws_bytes.restype = c_i64
+    lib.skhip_decode_stack.argtypes = [c_p, c_int] + [c_p] * 11 + [c_i64] + [c_int] * 8 + [c_f32, c_f32, c_int, c_p]
     lib.skhip_gather_rows.argtypes = [c_p] * 3 + [c_i64] * 4 + [c_int, c_p]
     for name in EXPORTS:
         getattr(lib, name)  # AttributeError here means header and library disagree
@@ -419,6 +423,35 @@ def beam_update(new_scores, prev, new_tok, scores, ys, ks, done, length, n_done,
                                   _ptr(pad_hist), _ptr(hist_in), _ptr(hist_out), n_sent, bm, Tc, max_len, pad_id, eos_id,
                                   _stream())
     _check(rc, "skhip_beam_update")
+
+
+def decode_stack_ws_bytes(R):
+    return int(load().skhip_decode_stack_ws_bytes(R))
+
+
+STACK_ERR_WORD = 64  # int32 index of the error word in the stack workspace
+
+
+def decode_stack_table(layer_tensors):
+    """Host table for decode_stack: per layer 22 device tensors in the order of the header."""
+    n = len(layer_tensors)
+    table = (c_i64 * (22 * n))()
+    for i, row in enumerate(layer_tensors):
+        assert len(row) == 22
+        table[22 * i:22 * i + 22] = [t.data_ptr() for t in row]
+    return table, n
+
+
+def decode_stack(table, n_layers, tok, pos, word_emb, pos_tab, cur_len, row_pad, pad_hist, hist, src_key_pad, dec_out,
+                 ws, R, bm, Tc, Ls, d_model, n_head, d_head, d_inner, scale, eps, parity):
+    """One decode step of the whole decoder stack (see the header); ws: uint8 workspace tensor."""
+    assert tok.dtype == pos.dtype == torch.int64 and cur_len.dtype == hist.dtype == torch.int32
+    assert dec_out.dtype == torch.bfloat16 and word_emb.dtype == pos_tab.dtype == torch.float32
+    rc = load().skhip_decode_stack(table, n_layers, _ptr(tok), _ptr(pos), _ptr(word_emb), _ptr(pos_tab), _ptr(cur_len),
+                                   _ptr(row_pad), _ptr(pad_hist), _ptr(hist), _ptr(src_key_pad), _ptr(dec_out), _ptr(ws),
+                                   ws.numel() * ws.element_size(), R, bm, Tc, Ls, d_model, n_head, d_head, d_inner,
+                                   float(scale), float(eps), int(parity), _stream())
+    _check(rc, "skhip_decode_stack")
 
 
 def gather_rows(src, dst, src_row, n_rows, row_elems, src_stride, dst_stride):

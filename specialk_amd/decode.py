@@ -26,12 +26,18 @@ from .core import constants as Constants
 
 
 class BeamDecoder:
-    def __init__(self, model, beam_size, max_token_seq_len, use_graph=None):
+    def __init__(self, model, beam_size, max_token_seq_len, use_graph=None, use_stack=None):
         self.model = model
         self.bm = int(beam_size)
         self.max_len = int(max_token_seq_len)
         # replay pairs of steps from a captured HIP graph (SK_DECODE_GRAPH=0: launch every step from the host)
         self.use_graph = os.environ.get("SK_DECODE_GRAPH", "1") != "0" if use_graph is None else bool(use_graph)
+        # run the decoder stack of a step as ONE launch where the shape allows it (bf16, d_model 512, 8 heads of 64,
+        # d_inner 2048, at most 32 x CUs / 8 beam rows); SK_DECODE_STACK=0: always op by op
+        self.use_stack = os.environ.get("SK_DECODE_STACK", "1") != "0" if use_stack is None else bool(use_stack)
+        # debugging aids (host-launched steps only): `trace` receives (decoder output, new_scores, prev, new_tok) of
+        # every step; `forced` replaces the search's choice of step i by forced[i] = (new_scores, prev, new_tok)
+        self.trace, self.forced = None, None
 
     _capture_streams = {}
 
@@ -139,9 +145,35 @@ class BeamDecoder:
             y, _, _ = L.add_ln_fwd(o, x, ln.weight.detach(), ln.bias.detach(), row_pad, ln.eps, 0.0, 0)
             return y
 
+        F = layers[0].pos_ffn.w_1.weight.shape[0]
+        stack = (self.use_stack and dt == torch.bfloat16 and (d, H, dk, dv, F) == (512, 8, 64, 64, 2048) and NL <= 8
+                 and R <= 32 * (torch.cuda.get_device_properties(dev).multi_processor_count // 8))
+        if stack:
+            f32 = lambda p: p.detach().float().contiguous()
+            rows, keep = [], []
+            for li, l in enumerate(layers):
+                s_, c_, f_ = l.slf_attn, l.enc_attn, l.pos_ffn
+                row = [qkv_w[li], qkv_b[li], self._w(s_.fc.weight, dt), f32(s_.fc.bias), f32(s_.layer_norm.weight),
+                       f32(s_.layer_norm.bias), self._w(c_.w_qs.weight, dt), f32(c_.w_qs.bias), self._w(c_.fc.weight, dt),
+                       f32(c_.fc.bias), f32(c_.layer_norm.weight), f32(c_.layer_norm.bias), self._w(f_.w_1.weight, dt),
+                       f32(f_.w_1.bias), self._w(f_.w_2.weight, dt), f32(f_.w_2.bias), f32(f_.layer_norm.weight),
+                       f32(f_.layer_norm.bias), Kc[li], Vc[li], crossK[li], crossV[li]]
+                rows.append(row)
+                keep.append(row)
+            stack_table, _ = L.decode_stack_table(rows)
+            stack_ws = torch.zeros(L.decode_stack_ws_bytes(R), dtype=torch.uint8, device=dev)
+            stack_out = torch.empty((R, d), dtype=dt, device=dev)
+            ln_eps = float(layers[0].slf_attn.layer_norm.eps)
+        self.used_stack = bool(stack)
+        step_no = [0]
+
         def step(first, cur):
             """One decoder step on the newest position of every beam, then the beam update; reads the history
             table hist[cur] and leaves the re-parented one in hist[cur ^ 1]."""
+            if stack:
+                L.decode_stack(stack_table, NL, tok, pos, word_emb, pos_tab, cur_len, row_pad, pad_hist, hist[cur],
+                               src_key_pad, stack_out, stack_ws, R, bm, Tc, Ls, d, H, dk, F, scale, ln_eps, cur)
+                return finish_step(stack_out, first, cur)
             x = L.embed_fwd(tok, pos, word_emb, pos_tab, dt)
             for li, layer in enumerate(layers):
                 a = layer.slf_attn
@@ -160,8 +192,17 @@ class BeamDecoder:
                 f = layer.pos_ffn
                 hbuf = proj(x, f.w_1, relu=True)
                 x = add_ln(proj(hbuf, f.w_2), x, f.layer_norm)
+            return finish_step(x, first, cur)
+
+        def finish_step(x, first, cur):
             logits = L.gemm(L.GEMM_NT, x, gen_w, R, V, d, d, d, out_dtype=torch.float32)
             L.beam_topk(logits, scores, n, bm, first_step=first, out=(new_scores, prev, new_tok))
+            if self.forced is not None:
+                for dst, src in zip((new_scores, prev, new_tok), self.forced[step_no[0]]):
+                    dst.copy_(src)
+            if self.trace is not None:
+                self.trace.append((x.clone(), new_scores.clone(), prev.clone(), new_tok.clone()))
+            step_no[0] += 1
             # finished sentences keep their final beam state (their Beam is no longer advanced)
             L.beam_update(new_scores, prev, new_tok, scores, ys, ks, done, length, n_done, cur_len, tok, pos, row_pad,
                           pad_hist, hist[cur], hist[cur ^ 1], n, bm, Tc, Tmax, Constants.PAD, Constants.EOS)
@@ -185,6 +226,8 @@ class BeamDecoder:
                 break
         del graph
         self.last_steps = steps
+        if stack and int(stack_ws[4 * L.STACK_ERR_WORD:4 * L.STACK_ERR_WORD + 4].view(torch.int32).item()) != 0:
+            raise RuntimeError("skhip_decode_stack: a team member stopped waiting for its team; results are invalid")
         if was_training:
             model.train()
 
