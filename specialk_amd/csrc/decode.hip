@@ -152,6 +152,11 @@ __device__ __forceinline__ void wave_argbest(float& v, int& i) {
 // Pass A: one block per (sentence, beam) row: log-sum-exp over V, then the row's best KC
 // tokens.  Candidate value = (x - max) - log(sum) + score_in, the same operation order as
 // F.log_softmax followed by `word_prob + scores` (Translator.py:137, Beam.py:52).
+// normalize == 2: as 1 with the hardware exponential (v_exp_f32, ~1 ulp) instead of expf in the normaliser; bf16
+// models decode with it, fp32 models keep expf and with it the reference's bits.
+// Measured and not kept: the row held in registers (one pass over memory, every load in flight at once): 102 us
+// against 67 us (fewer waves to issue the instructions that bound this kernel); one candidate list per WAVE with a
+// vote per element instead of a list per thread: 75 us against 61 us (a cross-lane arg-max per accepted element).
 template <int KC>
 __global__ __launch_bounds__(256) void beam_row_topk_kernel(const float* __restrict__ logits,
                                                             const float* __restrict__ scores_in,
@@ -189,10 +194,20 @@ __global__ __launch_bounds__(256) void beam_row_topk_kernel(const float* __restr
     }
   };
   const bool vec = (V & 3) == 0 && ((uintptr_t)x & 15) == 0;
-  if (vec) {  // two 16-byte loads in flight per thread
+  if (vec) {  // eight 16-byte loads in flight per thread (the row streams from HBM: a thread's share is ~35 loads)
     const float4* x4 = (const float4*)x;
     const int64_t n4 = V >> 2;
     int64_t c = threadIdx.x;
+    for (; c + 7 * 256 < n4; c += 8 * 256) {
+      float4 a[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a[u] = x4[c + 256 * u];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int64_t e = c + 256 * u;
+        visit(a[u].x, (int)(4 * e)); visit(a[u].y, (int)(4 * e + 1)); visit(a[u].z, (int)(4 * e + 2)); visit(a[u].w, (int)(4 * e + 3));
+      }
+    }
     for (; c + 256 < n4; c += 512) {
       const float4 a = x4[c], b = x4[c + 256];
       visit(a.x, (int)(4 * c)); visit(a.y, (int)(4 * c + 1)); visit(a.z, (int)(4 * c + 2)); visit(a.w, (int)(4 * c + 3));
@@ -214,12 +229,24 @@ __global__ __launch_bounds__(256) void beam_row_topk_kernel(const float* __restr
   float logse = 0.f;
   if (normalize) {
     float se = 0.f;
-    if (vec) {
+    if (vec) {   // four loads in flight, summed in the order of the plain loop
       const float4* x4 = (const float4*)x;
       float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-      for (int64_t c = threadIdx.x; c < (V >> 2); c += 256) {
+      const bool fast = normalize == 2;
+      auto ex = [&](float t) { return fast ? __expf(t) : expf(t); };
+      int64_t c = threadIdx.x;
+      for (; c + 3 * 256 < (V >> 2); c += 4 * 256) {
+        float4 q[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) q[u] = x4[c + 256 * u];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          s0 += ex(q[u].x - mx); s1 += ex(q[u].y - mx); s2 += ex(q[u].z - mx); s3 += ex(q[u].w - mx);
+        }
+      }
+      for (; c < (V >> 2); c += 256) {
         const float4 a = x4[c];
-        s0 += expf(a.x - mx); s1 += expf(a.y - mx); s2 += expf(a.z - mx); s3 += expf(a.w - mx);
+        s0 += ex(a.x - mx); s1 += ex(a.y - mx); s2 += ex(a.z - mx); s3 += ex(a.w - mx);
       }
       se = (s0 + s1) + (s2 + s3);
     } else {

@@ -196,7 +196,10 @@ class BeamDecoder:
 
         def finish_step(x, first, cur):
             logits = L.gemm(L.GEMM_NT, x, gen_w, R, V, d, d, d, out_dtype=torch.float32)
-            L.beam_topk(logits, scores, n, bm, first_step=first, out=(new_scores, prev, new_tok))
+            # (bf16 models: the normaliser's exponentials on the hardware instruction; fp32 models keep expf and the
+            # reference's bits)
+            L.beam_topk(logits, scores, n, bm, first_step=first, normalize=2 if dt == torch.bfloat16 else 1,
+                        out=(new_scores, prev, new_tok))
             if self.forced is not None:
                 for dst, src in zip((new_scores, prev, new_tok), self.forced[step_no[0]]):
                     dst.copy_(src)
