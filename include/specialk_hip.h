@@ -47,6 +47,9 @@ extern "C" {
 #define SK_EPI_RELU_BITS_OUT 16  /* with RELU: also write the sign pattern, one bit per element (bit n%16 of
                                     uint16 word (m*N + n)/16), to aux                           */
 #define SK_EPI_RELU_MASK_BITS 32 /* as RELU_MASK, with aux holding such a bit pattern (1/16 of the bytes) */
+#define SK_EPI_ROWSTATS 64  /* plain bf16 NT product with fp32 output only: aux (fp32 [M][ceil(N/64)][2]) receives, per
+                              row and 64-column chunk, the maximum and the sum of exp(x - maximum): what a log-softmax
+                              and a top-k over the rows need to know about the chunks they do not read */
 
 const char* skhip_version(void);
 const char* skhip_last_error(void);
@@ -322,6 +325,15 @@ int64_t skhip_beam_topk_ws_bytes(int n_sent, int bm, int64_t V);
 int skhip_beam_topk(const float* logits, const float* scores_in, float* scores_out,
                     int32_t* prev_out, int32_t* tok_out, void* ws, int n_sent, int bm, int64_t V,
                     int first_step, int normalize, void* stream);
+
+/* skhip_beam_topk (normalize = 1) for rows whose generator product was run with SK_EPI_ROWSTATS: `stats` is that
+ * call's aux output (fp32 [n_sent*bm][ceil(V/64)][2]).  The normaliser comes from the statistics and only the 64-column
+ * chunks that can hold one of a row's best bm tokens are read, instead of every row twice.  Same candidates, same
+ * order and tie rule; scores agree with skhip_beam_topk to fp32 rounding (the exponentials are summed chunk by chunk,
+ * with the hardware exponential).  V <= 65 536.  ws as for skhip_beam_topk.                                        */
+int skhip_beam_topk_stats(const float* logits, const float* stats, const float* scores_in, float* scores_out,
+                          int32_t* prev_out, int32_t* tok_out, void* ws, int n_sent, int bm, int64_t V,
+                          int first_step, void* stream);
 
 /* One decode step of the WHOLE decoder stack in one launch (bf16; d_model 512, 8 heads of 64, d_inner 2048 — other
  * shapes: SK_ERR_ARG, use the entry points above op by op).  Replaces, for the newest position of every beam row,

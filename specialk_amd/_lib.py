@@ -12,7 +12,7 @@ import torch
 
 SK_F32, SK_BF16 = 0, 1
 GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
-EPI_BIAS, EPI_RELU, EPI_RELU_MASK, EPI_ACCUM, EPI_RELU_BITS_OUT, EPI_RELU_MASK_BITS = 1, 2, 4, 8, 16, 32
+EPI_BIAS, EPI_RELU, EPI_RELU_MASK, EPI_ACCUM, EPI_RELU_BITS_OUT, EPI_RELU_MASK_BITS, EPI_ROWSTATS = 1, 2, 4, 8, 16, 32, 64
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libspecialk_hip.so")
@@ -23,7 +23,7 @@ EXPORTS = [
     "skhip_attn_bwd", "skhip_attn_varlen_fwd", "skhip_attn_varlen_bwd", "skhip_add_ln_fwd", "skhip_add_ln_bwd_ws_floats", "skhip_add_ln_bwd", "skhip_embed_fwd",
     "skhip_embed_bwd", "skhip_pack_plan", "skhip_xent_fwd_bwd", "skhip_adam_multi", "skhip_cast_multi", "skhip_cast2d_multi", "skhip_convert",
     "skhip_decode_attn", "skhip_beam_topk_ws_bytes", "skhip_beam_topk", "skhip_beam_update", "skhip_gather_rows",
-    "skhip_decode_stack_ws_bytes", "skhip_decode_stack",
+    "skhip_decode_stack_ws_bytes", "skhip_decode_stack", "skhip_beam_topk_stats",
     "skhip_softmax_rows", "skhip_conv_windows", "skhip_cnn_head", "skhip_collate",
 ]
 
@@ -73,6 +73,7 @@ def load():
     lib.skhip_convert.argtypes = [c_p, c_p, c_i64, c_int, c_int, c_p]
     lib.skhip_decode_attn.argtypes = [c_p] * 9 + [c_i64] + [c_int] * 6 + [c_i64, c_i64, c_f32, c_int, c_int, c_p]
     lib.skhip_beam_topk.argtypes = [c_p] * 6 + [c_int, c_int, c_i64, c_int, c_int, c_p]
+    lib.skhip_beam_topk_stats.argtypes = [c_p] * 7 + [c_int, c_int, c_i64, c_int, c_p]
     lib.skhip_beam_update.argtypes = [c_p] * 16 + [c_int] * 6 + [c_p]
     lib.skhip_decode_stack_ws_bytes.argtypes = [c_int]
     lib.skhip_decode_stack_ws_bytes.restype = c_i64
@@ -410,6 +411,19 @@ def beam_topk(logits, scores_in, n_sent, bm, first_step, normalize=True, out=Non
     rc = lib.skhip_beam_topk(_ptr(logits), _ptr(scores_in), _ptr(scores_out), _ptr(prev), _ptr(tok), _ptr(ws),
                              n_sent, bm, V, int(first_step), int(normalize), _stream())
     _check(rc, "skhip_beam_topk")
+    return scores_out, prev, tok
+
+
+def beam_topk_stats(logits, stats, scores_in, n_sent, bm, first_step, out):
+    """beam_topk for logits whose generator product left chunk statistics (EPI_ROWSTATS) in `stats`."""
+    lib = load()
+    V = logits.shape[-1]
+    scores_out, prev, tok = out
+    assert logits.dtype == stats.dtype == torch.float32 and stats.numel() >= n_sent * bm * ((V + 63) // 64) * 2
+    ws = workspace(int(lib.skhip_beam_topk_ws_bytes(n_sent, bm, V)))
+    rc = lib.skhip_beam_topk_stats(_ptr(logits), _ptr(stats), _ptr(scores_in), _ptr(scores_out), _ptr(prev), _ptr(tok),
+                                   _ptr(ws), n_sent, bm, V, int(first_step), _stream())
+    _check(rc, "skhip_beam_topk_stats")
     return scores_out, prev, tok
 
 

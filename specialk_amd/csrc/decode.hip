@@ -287,6 +287,120 @@ __global__ __launch_bounds__(256) void beam_row_topk_kernel(const float* __restr
   }
 }
 
+// Pass A with chunk statistics: the generator product has left, per row and 64-column chunk, the chunk's maximum
+// and its sum of exponentials against that maximum (SK_EPI_ROWSTATS).  One wave per row: the normaliser comes from
+// the statistics alone, and only the chunks whose maximum reaches the bm-th largest chunk maximum can hold one of the
+// row's best bm tokens (the bm largest chunk maxima are bm different elements, so the bm-th best element is at
+// least the bm-th largest chunk maximum, and every better element lifts its chunk's maximum above it): those few
+// chunks are read, 64 logits at a time, instead of the whole row twice.  Same (value, index) order as above.
+constexpr int STAT_SLOTS = 16;   // chunk statistics per lane: rows of up to 64 * 64 * 16 = 65 536 tokens
+template <int KC>
+__global__ __launch_bounds__(64) void beam_row_topk_stats_kernel(const float* __restrict__ logits,
+                                                                 const float2* __restrict__ stats,
+                                                                 const float* __restrict__ scores_in,
+                                                                 float* __restrict__ cand_val, int32_t* __restrict__ cand_idx,
+                                                                 int bm, int64_t V, int first_step) {
+  const int row = blockIdx.x, beam = row % bm, lane = threadIdx.x;
+  float* cv = cand_val + (int64_t)row * bm;
+  int32_t* ci = cand_idx + (int64_t)row * bm;
+  if (first_step && beam != 0) {
+    if (lane < bm) { cv[lane] = -INFINITY; ci[lane] = 0x7fffffff; }
+    return;
+  }
+  const int nchunk = (int)((V + 63) >> 6);
+  const float2* st = stats + (int64_t)row * nchunk;
+  float cm[STAT_SLOTS], cs[STAT_SLOTS];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int u = 0; u < STAT_SLOTS; ++u) {
+    const int c = lane + 64 * u;
+    const float2 v = c < nchunk ? st[c] : make_float2(-INFINITY, 0.f);
+    cm[u] = v.x; cs[u] = v.y;
+    mx = fmaxf(mx, v.x);
+  }
+  mx = wave_max(mx);
+  float se = 0.f;
+#pragma unroll
+  for (int u = 0; u < STAT_SLOTS; ++u) se += cm[u] == -INFINITY ? 0.f : cs[u] * __expf(cm[u] - mx);
+  se = wave_sum(se);
+  const float logse = logf(se);
+  // the bm-th largest chunk maximum: bm rounds of (best remaining, lowest chunk on ties)
+  float rem[STAT_SLOTS];
+#pragma unroll
+  for (int u = 0; u < STAT_SLOTS; ++u) rem[u] = cm[u];
+  float thr = -INFINITY;
+  for (int round = 0; round < bm; ++round) {
+    float bv = -INFINITY; int bc = 0x7fffffff;
+#pragma unroll
+    for (int u = 0; u < STAT_SLOTS; ++u)
+      if (better(rem[u], lane + 64 * u, bv, bc)) { bv = rem[u]; bc = lane + 64 * u; }
+    wave_argbest(bv, bc);
+    thr = bv;
+#pragma unroll
+    for (int u = 0; u < STAT_SLOTS; ++u) if (lane + 64 * u == bc) rem[u] = -INFINITY;
+  }
+  // thread-local top-KC over the candidate chunks' elements (a lane sees one element per chunk)
+  float tv[KC];
+  int ti[KC];
+#pragma unroll
+  for (int k = 0; k < KC; ++k) { tv[k] = -INFINITY; ti[k] = 0x7fffffff; }
+  const float* x = logits + (int64_t)row * V;
+  auto visit = [&](float v, int idx) {
+    if (better(v, idx, tv[KC - 1], ti[KC - 1])) {
+      tv[KC - 1] = v; ti[KC - 1] = idx;
+#pragma unroll
+      for (int k = KC - 1; k > 0; --k)
+        if (better(tv[k], ti[k], tv[k - 1], ti[k - 1])) {
+          float fv = tv[k]; tv[k] = tv[k - 1]; tv[k - 1] = fv;
+          int fi = ti[k]; ti[k] = ti[k - 1]; ti[k - 1] = fi;
+        }
+    }
+  };
+  // the candidate chunks, eight at a time with their loads in flight together (there are bm of them unless chunk
+  // maxima tie)
+  constexpr int BATCH = 8;
+  int batch[BATCH], nb = 0;
+  auto flush = [&]() {
+    float v[BATCH];
+#pragma unroll
+    for (int k = 0; k < BATCH; ++k) {
+      const int64_t c = 64 * (int64_t)batch[k < nb ? k : 0] + lane;
+      v[k] = (k < nb && c < V) ? x[c < V ? c : 0] : -INFINITY;
+    }
+#pragma unroll
+    for (int k = 0; k < BATCH; ++k) {
+      const int64_t c = 64 * (int64_t)batch[k < nb ? k : 0] + lane;
+      if (k < nb) visit(v[k], c < V ? (int)c : 0x7fffffff);
+    }
+    nb = 0;
+  };
+#pragma unroll 1
+  for (int u = 0; u < STAT_SLOTS; ++u) {
+    uint64_t todo = __ballot(cm[u] >= thr && cm[u] != -INFINITY);
+    while (todo) {
+      batch[nb++] = __builtin_ctzll(todo) + 64 * u;
+      todo &= todo - 1;
+      if (nb == BATCH) flush();
+    }
+  }
+  if (nb) flush();
+  const float sc = first_step ? 0.f : scores_in[row];
+  for (int round = 0; round < bm; ++round) {
+    float bv = tv[0]; int bi = ti[0];
+    wave_argbest(bv, bi);
+    if (lane == 0) {
+      const float lp = (bv - mx) - logse;
+      cv[round] = first_step ? lp : lp + sc;
+      ci[round] = bi;
+    }
+    if (ti[0] == bi && bi != 0x7fffffff) {
+#pragma unroll
+      for (int k = 0; k < KC - 1; ++k) { tv[k] = tv[k + 1]; ti[k] = ti[k + 1]; }
+      tv[KC - 1] = -INFINITY; ti[KC - 1] = 0x7fffffff;
+    }
+  }
+}
+
 // Pass B: one wave per sentence merges its bm*bm row candidates into the new beam,
 // ordered like flat_beam_lk.topk(size, 0, True, True) with flat id = beam*V + token.
 __global__ __launch_bounds__(64) void beam_merge_kernel(const float* __restrict__ cand_val,
@@ -452,6 +566,31 @@ extern "C" int skhip_beam_topk(const float* logits, const float* scores_in, floa
   SK_CHECK_LAUNCH("skhip_beam_topk(rows)");
   hipLaunchKernelGGL(beam_merge_kernel, dim3((unsigned)n_sent), dim3(64), 0, stream, cv, ci, scores_out, prev_out, tok_out, bm, V);
   SK_CHECK_LAUNCH("skhip_beam_topk(merge)");
+  return SK_OK;
+}
+
+extern "C" int skhip_beam_topk_stats(const float* logits, const float* stats, const float* scores_in, float* scores_out,
+                                     int32_t* prev_out, int32_t* tok_out, void* ws, int n_sent, int bm, int64_t V,
+                                     int first_step, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SK_CHECK_ARG(bm >= 1 && bm <= 16, "skhip_beam_topk_stats: beam size %d not in 1..16", bm);
+  SK_CHECK_ARG(V >= bm && V <= 64 * 64 * STAT_SLOTS, "skhip_beam_topk_stats: V=%lld not in bm..65536", (long long)V);
+  if (n_sent == 0) return SK_OK;
+  SK_CHECK_ARG(logits && stats && scores_in && scores_out && prev_out && tok_out && ws && (uintptr_t)stats % 8 == 0,
+               "skhip_beam_topk_stats: null or misaligned pointer");
+  float* cv = (float*)ws;
+  int32_t* ci = (int32_t*)(cv + (int64_t)n_sent * bm * bm);
+  dim3 grid((unsigned)(n_sent * bm));
+#define BEAM_S(KC) hipLaunchKernelGGL((beam_row_topk_stats_kernel<KC>), grid, dim3(64), 0, stream, logits, (const float2*)stats, scores_in, cv, ci, bm, V, first_step)
+  if (bm <= 1) BEAM_S(1);
+  else if (bm <= 2) BEAM_S(2);
+  else if (bm <= 4) BEAM_S(4);
+  else if (bm <= 8) BEAM_S(8);
+  else BEAM_S(16);
+#undef BEAM_S
+  SK_CHECK_LAUNCH("skhip_beam_topk_stats(rows)");
+  hipLaunchKernelGGL(beam_merge_kernel, dim3((unsigned)n_sent), dim3(64), 0, stream, cv, ci, scores_out, prev_out, tok_out, bm, V);
+  SK_CHECK_LAUNCH("skhip_beam_topk_stats(merge)");
   return SK_OK;
 }
 

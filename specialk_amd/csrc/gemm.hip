@@ -233,6 +233,29 @@ __device__ __forceinline__ void write_tile(const GemmParams& p, const f32x4_t (*
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[ni * 4 + r] = acc[mi][ni][r];
       write_cols<TOut, TIn, 16>(p, v, row, col0 + 16 * g, slab);
+      if constexpr (sizeof(TOut) == 4) {
+        // SK_EPI_ROWSTATS (plain fp32 products only: v is what was stored): maximum and sum of exponentials
+        // against it over the 64 columns this wave holds of the row (the four lanes l, l + 16, l + 32, l + 48)
+        if (p.epi & SK_EPI_ROWSTATS) {
+          const int c0 = col0 + 16 * g;
+          float m = -INFINITY;
+#pragma unroll
+          for (int j = 0; j < 16; ++j) m = fmaxf(m, c0 + j < p.N ? v[j] : -INFINITY);
+          float se = 0.f;
+#pragma unroll
+          for (int j = 0; j < 16; ++j) se += c0 + j < p.N ? __expf(v[j] - m) : 0.f;
+          if (m == -INFINITY) se = 0.f;
+#pragma unroll
+          for (int o = 16; o < 64; o <<= 1) {
+            const float om = __shfl_xor(m, o, 64), os = __shfl_xor(se, o, 64);
+            const float nm = fmaxf(m, om);
+            se = (m == -INFINITY ? 0.f : se * __expf(m - nm)) + (om == -INFINITY ? 0.f : os * __expf(om - nm));
+            m = nm;
+          }
+          if (g == 0 && col0 < p.N)
+            *(float2*)((float*)p.aux + 2 * ((int64_t)row * ((p.N + 63) >> 6) + (col0 >> 6))) = make_float2(m, se);
+        }
+      }
     } else {
 #pragma unroll
       for (int ni = 0; ni < 4; ++ni) {
@@ -1417,6 +1440,12 @@ static int gemm_one(int layout, const void* A, const void* B, void* C, const voi
                  "skhip_gemm: sign-pattern epilogues are for bf16 NT products with N %% 64 == 0");
     workspace = nullptr;  // the pattern is written / applied in the epilogue: no split-K
   }
+  if (epilogue & SK_EPI_ROWSTATS) {
+    SK_CHECK_ARG(epilogue == SK_EPI_ROWSTATS && alpha == 1.0f && aux && (uintptr_t)aux % 8 == 0 && in_dtype == SK_BF16 &&
+                 out_dtype == SK_F32 && layout == SK_GEMM_NT,
+                 "skhip_gemm: SK_EPI_ROWSTATS is for plain bf16 NT products with fp32 output (alpha 1, no other epilogue)");
+    workspace = nullptr;  // the statistics are taken in the epilogue: no split-K
+  }
   const bool a_t = layout == SK_GEMM_TN, b_t = layout != SK_GEMM_NT;
   SK_CHECK_ARG(lda >= (a_t ? M : K) && ldb >= (b_t ? N : K) && ldc >= N, "skhip_gemm: leading dimension too small");
 
@@ -1492,6 +1521,11 @@ static int gemm_one(int layout, const void* A, const void* B, void* C, const voi
     use_big = ((M + 255) / 256) * ((N + 255) / 256) >= 12;
   if (env_big && env_big[0] == '0') use_big = false;
   if (env_big && env_big[0] == '1') use_big = in_dtype == SK_BF16 && fast;
+  if (epilogue & SK_EPI_ROWSTATS) {  // the statistics hook lives in the 128-tile kernel's epilogue
+    SK_CHECK_ARG(fast, "skhip_gemm: SK_EPI_ROWSTATS needs 16-byte aligned operands with K %% 8 == 0");
+    use_big = false;
+    use_staged = false;
+  }
   if (use_big) {
     p.tiles_m = (int)((M + b16x::XM - 1) / b16x::XM);
     p.tiles_n = (int)((N + b16x::XN - 1) / b16x::XN);

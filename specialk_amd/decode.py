@@ -165,6 +165,10 @@ class BeamDecoder:
             stack_out = torch.empty((R, d), dtype=dt, device=dev)
             ln_eps = float(layers[0].slf_attn.layer_norm.eps)
         self.used_stack = bool(stack)
+        use_stats = (dt == torch.bfloat16 and d % 8 == 0 and V <= 65536 and os.environ.get("SK_DECODE_TOPK_STATS", "1") != "0")
+        if use_stats:
+            logits_buf = torch.empty((R, V), dtype=torch.float32, device=dev)
+            gen_stats = torch.empty((R, (V + 63) // 64, 2), dtype=torch.float32, device=dev)
         step_no = [0]
 
         def step(first, cur):
@@ -195,11 +199,16 @@ class BeamDecoder:
             return finish_step(x, first, cur)
 
         def finish_step(x, first, cur):
-            logits = L.gemm(L.GEMM_NT, x, gen_w, R, V, d, d, d, out_dtype=torch.float32)
-            # (bf16 models: the normaliser's exponentials on the hardware instruction; fp32 models keep expf and the
-            # reference's bits)
-            L.beam_topk(logits, scores, n, bm, first_step=first, normalize=2 if dt == torch.bfloat16 else 1,
-                        out=(new_scores, prev, new_tok))
+            if use_stats:
+                # bf16 models: the generator product also leaves each 64-column chunk's maximum and sum of exponentials;
+                # the top-k then reads those and the few chunks that can hold a best token, not every row twice
+                L.gemm(L.GEMM_NT, x, gen_w, R, V, d, d, d, out=logits_buf, ldc=V, aux=gen_stats, epilogue=L.EPI_ROWSTATS,
+                       split_k=False)
+                L.beam_topk_stats(logits_buf, gen_stats, scores, n, bm, first, out=(new_scores, prev, new_tok))
+            else:  # fp32 models keep expf and the reference's bits
+                logits = L.gemm(L.GEMM_NT, x, gen_w, R, V, d, d, d, out_dtype=torch.float32)
+                L.beam_topk(logits, scores, n, bm, first_step=first, normalize=2 if dt == torch.bfloat16 else 1,
+                            out=(new_scores, prev, new_tok))
             if self.forced is not None:
                 for dst, src in zip((new_scores, prev, new_tok), self.forced[step_no[0]]):
                     dst.copy_(src)

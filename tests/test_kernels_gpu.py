@@ -634,6 +634,44 @@ def test_beam_topk(L, bm):
                 np.testing.assert_allclose(so[s].cpu().numpy(), best, rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("V,bm,rows_of", [(35000, 5, 128), (1003, 5, 7), (4096, 3, 11), (200, 16, 2)])
+def test_beam_topk_from_generator_statistics(L, V, bm, rows_of):
+    """SK_EPI_ROWSTATS + skhip_beam_topk_stats (the bf16 decode step's form) against the plain product +
+    skhip_beam_topk: the same logits bit for bit, chunk statistics equal to torch's, the same tokens and
+    back-pointers — with duplicated weight rows, i.e. exact ties between tokens of one row, inside a chunk and
+    across chunks, and V not a multiple of 64 — and scores to fp32 rounding."""
+    g = torch.Generator().manual_seed(V + bm)
+    n_sent, d = rows_of, 512
+    R = n_sent * bm
+    x = rnd((R, d), torch.bfloat16, g).to(DEV)
+    W = (rnd((V, d), torch.bfloat16, g) * 0.2)
+    W[9] = W[3]            # a tie inside a chunk
+    if V > 150:
+        W[140] = W[3]      # ... and across chunks
+        W[V - 1] = W[V - 2]
+    W = W.to(DEV)
+    scores = (-torch.rand(n_sent, bm, generator=g) * 5).to(DEV)
+    plain = L.gemm(L.GEMM_NT, x, W, R, V, d, d, d, out_dtype=torch.float32, split_k=False)
+    logits = torch.empty((R, V), dtype=torch.float32, device=DEV)
+    nch = (V + 63) // 64
+    stats = torch.full((R, nch, 2), float("nan"), dtype=torch.float32, device=DEV)
+    L.gemm(L.GEMM_NT, x, W, R, V, d, d, d, out=logits, ldc=V, aux=stats, epilogue=L.EPI_ROWSTATS, split_k=False)
+    assert torch.equal(logits, plain)
+    pad = torch.full((R, nch * 64), float("-inf"), dtype=torch.float64, device=DEV)
+    pad[:, :V] = logits.double()
+    ch = pad.view(R, nch, 64)
+    m = ch.max(2).values
+    se = torch.exp(ch - m[:, :, None]).sum(2)
+    assert torch.equal(stats[:, :, 0].double(), m)
+    assert rel_err(stats[:, :, 1], se) <= 1e-5
+    for first in (True, False):
+        so, prev, tok = L.beam_topk(logits, scores, n_sent, bm, first)
+        out = (torch.empty_like(so), torch.empty_like(prev), torch.empty_like(tok))
+        so2, prev2, tok2 = L.beam_topk_stats(logits, stats, scores, n_sent, bm, first, out)
+        assert torch.equal(prev2, prev) and torch.equal(tok2, tok), (V, bm, first)
+        assert (so2 - so).abs().max().item() <= 2e-5
+
+
 def test_gather_rows(L):
     g = torch.Generator().manual_seed(6)
     for dtype, elems in ((torch.float32, 96), (torch.bfloat16, 100), (torch.bfloat16, 64)):
