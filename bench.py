@@ -237,7 +237,8 @@ def decode_leg(device, n_batches=10, batch=128, beam=5, max_len=150, copy_task_s
     not leave that task's initial plateau within a few thousand steps, in fp32 or bf16).
     HBM roofline of the worst case: algorithmic bytes of one step at history length t — self-attention keys and
     values of t positions for every beam row, encoder-side keys / values once per sentence, the decoder's and
-    generator's bf16 weights once, the fp32 log-probabilities written once and read twice (normalisation, top-k) —
+    generator's bf16 weights once, the fp32 log-probabilities written once (the top-k reads chunk statistics and a few
+    chunks per row) —
     summed over the steps, divided by the time."""
     from specialk_amd import ops
     from specialk_amd.decode import BeamDecoder
@@ -313,7 +314,8 @@ def decode_step_bytes(m, n, bm, Ls, steps):
     kv_row = H * (dk + dv) * 2                                   # bytes of one cached position (bf16)
     # per layer: self-attention q, k, v, output projections; cross-attention q and output projections; the two FFN matrices
     weights = NL * (3 * H * dk * d + 3 * H * dv * d + 2 * d * F) * 2 + V * d * 2
-    per_step_fixed = weights + NL * n * Ls * kv_row + 3 * R * V * 4
+    # fp32 log-probabilities written once; the top-k reads their 64-column chunk statistics and a few chunks per row
+    per_step_fixed = weights + NL * n * Ls * kv_row + R * V * 4 + 2 * R * ((V + 63) // 64) * 8 + R * 8 * 64 * 4
     hist = NL * R * kv_row * (steps * (steps + 1) / 2)           # sum over t = 1..steps of t positions
     return steps * per_step_fixed + hist
 
