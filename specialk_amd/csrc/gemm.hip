@@ -60,6 +60,7 @@ struct GemmParams {
   int vec_c;  // C (and aux) allow 16-byte vector access
   float alpha;
   int group;  // tile rows per rasterisation group (see tile_of)
+  int tile_h; // 256-tile kernel, K-contiguous A: rows of a tile actually computed (a multiple of 16, <= 256)
   // TN products of the grouped launch only: also out[m] (+)= sum_k A[k][m], the column sums of the first operand
   // (the bias gradient that belongs to a weight gradient dy^T x); null otherwise
   float* colsum;
@@ -218,14 +219,14 @@ __device__ __forceinline__ int grid_slab() { return gridDim.z > 1 ? (int)blockId
 
 // acc[mi][ni] holds C^T tiles: lane l owns output row 16*mi + (l & 15); register r of tile ni
 // is output column  PERM ? 16*(l>>4) + 4*ni + r  :  16*ni + 4*(l>>4) + r   (wave-local).
-template <typename TOut, typename TIn, bool PERM>
+template <typename TOut, typename TIn, bool PERM, int NG = 4>
 __device__ __forceinline__ void write_tile(const GemmParams& p, const f32x4_t (*acc)[4], int row0, int col0, int lane,
-                                           int slab) {
+                                           int slab, int row_end) {
   const int g = lane >> 4;
 #pragma unroll
-  for (int mi = 0; mi < 4; ++mi) {
+  for (int mi = 0; mi < NG; ++mi) {
     const int row = row0 + mi * 16 + (lane & 15);
-    if (row >= p.M) continue;
+    if (row >= row_end) continue;
     if (PERM) {
       float v[16];
 #pragma unroll
@@ -266,8 +267,8 @@ __device__ __forceinline__ void write_tile(const GemmParams& p, const f32x4_t (*
   }
 }
 
-// Epilogue of a FULL interior 128 x 64 wave tile of the 256-tile kernels in the permuted layout (a lane owns
-// 16 consecutive columns of one row in each of the eight 16-row groups; 16-byte aligned C, bias and pattern).
+// Epilogue of a FULL interior wave tile (NMI 16-row groups x 64 columns) of the 256-tile kernels in the permuted
+// layout (a lane owns 16 consecutive columns of one row in each of the groups; 16-byte aligned C, bias and pattern).
 // write_tile above handles one row group at a time: load what the epilogue reads, wait, store, eight times in
 // a row, each time exposing a full memory round trip.  Here the bias is fetched once per tile and the old C
 // values (accumulate form) and sign-pattern words of a PAIR of row groups are requested together, so a tile
@@ -332,7 +333,7 @@ __device__ __forceinline__ void load2x32_2x8_wait(const void* p0, const void* p1
       : "memory");
 }
 
-template <typename TOut>
+template <typename TOut, int NMI>
 __device__ __forceinline__ void write_wave_tile_full(const GemmParams& p, const f32x4_t (*acc)[4], int row0, int col0,
                                                      int lane, char* scratch) {
   const int g = lane >> 4, col = col0 + 16 * g;
@@ -352,9 +353,11 @@ __device__ __forceinline__ void write_wave_tile_full(const GemmParams& p, const 
   const int q = (col >> 4) & 3;  // which 16-column quarter of the 64-column pattern word this lane holds
 #pragma unroll
   for (int pair = 0; pair < 4; ++pair) {
+    if (2 * pair >= NMI) break;  // NMI: the wave's 16-row groups
+    const bool second = 2 * pair + 1 < NMI;
     uint4 oldc[2][2];
     uint2 words[2];
-    const int64_t r0 = row0 + (2 * pair) * 16 + (lane & 15), r1 = r0 + 16;
+    const int64_t r0 = row0 + (2 * pair) * 16 + (lane & 15), r1 = second ? r0 + 16 : r0;
     const void* c0 = (const bf16_t*)p.C + r0 * p.ldc + col;
     const void* c1 = (const bf16_t*)p.C + r1 * p.ldc + col;
     const void* w0 = (const uint64_t*)p.aux + ((r0 * p.N + col) >> 6);
@@ -364,7 +367,8 @@ __device__ __forceinline__ void write_wave_tile_full(const GemmParams& p, const 
     else if (maskb) load2x8_wait(w0, w1, words[0], words[1]);
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
-      const int mi = 2 * pair + m;
+      const int mi = (m == 1 && !second) ? 0 : 2 * pair + m;  // (index kept in range; the iteration is skipped)
+      if (m == 1 && !second) continue;
       const int64_t row = m ? r1 : r0;
       float v[16];
 #pragma unroll
@@ -586,7 +590,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
     }
     __syncthreads();
   }
-  write_tile<TOut, bf16_t, !B_T>(p, acc, m0 + wrow, n0 + wcol, lane, grid_slab());
+  write_tile<TOut, bf16_t, !B_T>(p, acc, m0 + wrow, n0 + wcol, lane, grid_slab(), p.M);
 }
 }  // namespace b16
 
@@ -741,7 +745,7 @@ __global__ __launch_bounds__(256, 3) void gemm_kernel(GemmParams p) {
     cs = cs == STAGES - 1 ? 0 : cs + 1;
     is = is == STAGES - 1 ? 0 : is + 1;
   }
-  write_tile<TOut, bf16_t, !B_T>(p, acc, m0 + wrow, n0 + wcol, lane, grid_slab());
+  write_tile<TOut, bf16_t, !B_T>(p, acc, m0 + wrow, n0 + wcol, lane, grid_slab(), p.M);
 }
 }  // namespace b16g
 
@@ -801,7 +805,9 @@ struct Loader {
   int64_t step;
   int kofs[2];
   bool rows_ok[2];
-  __device__ __forceinline__ void init(const bf16_t* base, int64_t ld, int r0, int R, int kbeg, int wave, int lane) {
+  // rows_used: rows of the 256-row image that the tile reads (the others are filled with zeros)
+  __device__ __forceinline__ void init(const bf16_t* base, int64_t ld, int r0, int R, int kbeg, int wave, int lane,
+                                       int rows_used) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int idx = wave * 2 + j;
@@ -816,7 +822,7 @@ struct Loader {
         const int row = 16 * idx + (lane >> 2), cpos = lane & 3;
         const int c = cpos ^ (IS_B ? key_kb(row) : key_ka(row));
         kofs[j] = 8 * c;
-        rows_ok[j] = true;
+        rows_ok[j] = 16 * idx < rows_used;
         ptr[j] = (const char*)(base + (int64_t)min(r0 + row, R - 1) * ld + kbeg + 8 * c);
         step = BK * 2;
       }
@@ -825,7 +831,7 @@ struct Loader {
   __device__ __forceinline__ void issue(char* lds, int wave_u, int k0, int kend) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      const bool ok = T_LAYOUT ? (rows_ok[j] && k0 + kofs[j] < kend) : (k0 + kofs[j] + 8 <= kend);
+      const bool ok = rows_ok[j] && (T_LAYOUT ? k0 + kofs[j] < kend : k0 + kofs[j] + 8 <= kend);
       const char* src = ok ? ptr[j] : (const char*)g_zero_page;
       __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(lds + (wave_u * 2 + j) * 1024), 16, 0, 0);
       ptr[j] += step;
@@ -849,23 +855,29 @@ __device__ __forceinline__ bf16x8_t read_frag(const char* image, int off) {
 
 // One 256 x 256 output tile over K range [kbeg, kend): the whole block's work.  slab >= 0 sends the
 // raw partial sums to that split-K slab instead of the epilogue.
-template <bool A_T, bool B_T, typename TOut>
-__device__ __forceinline__ void gemm_tile(const GemmParams& p, int tile_m, int tile_n, int kbeg, int kend, int slab) {
+// With a K-contiguous A the tile may be lower than 256 rows (p.tile_h, a multiple of 16, at least 144): one
+// block per CU means a launch takes whole rounds of the chip, and 25.6 k rows are 100.2 tiles of 256 — with
+// N = 512 that is 202 blocks on 256 CUs, with N = 2048 three rounds and an eighth.  Tiles of 208 rows make it 248
+// blocks, or four rounds that are full, of proportionally shorter tiles.  The rows above tile_h are loaded as
+// zeros and the upper wave half skips their MFMAs and stores.
+// NMI: the 16-row groups this wave computes, wrow: its first row inside the tile, th: the tile's rows.
+template <bool A_T, bool B_T, typename TOut, int NMI>
+__device__ __forceinline__ void gemm_tile_part(const GemmParams& p, int tile_m, int tile_n, int kbeg, int kend, int slab,
+                                               int wave, int wrow, int th) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int m0 = tile_m * XM, n0 = tile_n * XN;
-  const int wrow = (wave >> 2) * 128, wcol = (wave & 3) * 64;
+  const int m0 = tile_m * th, n0 = tile_n * XN;
+  const int wcol = (wave & 3) * 64;
   const int nk = (kend - kbeg + BK - 1) / BK;
 
   Loader<A_T, false> la;
   Loader<B_T, true> lb;
-  la.init((const bf16_t*)p.A, p.lda, m0, p.M, kbeg, wave, lane);
-  lb.init((const bf16_t*)p.B, p.ldb, n0, p.N, kbeg, wave, lane);
+  la.init((const bf16_t*)p.A, p.lda, m0, p.M, kbeg, wave, lane, th);
+  lb.init((const bf16_t*)p.B, p.ldb, n0, p.N, kbeg, wave, lane, XN);
 
-  f32x4_t acc[8][4];
+  f32x4_t acc[NMI][4];
 #pragma unroll
-  for (int i = 0; i < 8; ++i)
+  for (int i = 0; i < NMI; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
@@ -884,11 +896,11 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, int tile_m, int t
   if (wave >= 4) __builtin_amdgcn_s_barrier();  // upper half runs half a K-step behind
 
   // per-lane fragment offsets inside a stage
-  int offa[8], offb[4];
+  int offa[NMI], offb[4];
   {
     const int l15 = lane & 15, g = lane >> 4;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < NMI; ++i) {
       if (A_T) {
         offa[i] = t_off256(8 * g + (l15 >> 2), wrow + 16 * i + 4 * (l15 & 3));
       } else {
@@ -924,11 +936,11 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, int tile_m, int t
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     const char* st = smem + cs * STAGE_BYTES;
-    bf16x8_t fb[4], fa[8];
+    bf16x8_t fb[4], fa[NMI];
 #pragma unroll
     for (int i = 0; i < 4; ++i) fb[i] = read_frag<B_T>(st, offb[i]);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) fa[i] = read_frag<A_T>(st, offa[i]);
+    for (int i = 0; i < NMI; ++i) fa[i] = read_frag<A_T>(st, offa[i]);
     if (kt + 3 < nk) issue(is, kt + 3);
     // ---- M: tile kt+1 landed (this wave's part), own LDS reads done, then multiply
     if (kt + 3 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
@@ -940,11 +952,11 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, int tile_m, int t
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-    for (int mi = 0; mi < 8; ++mi)
+    for (int mi = 0; mi < NMI; ++mi)
 #pragma unroll
       for (int ni = 0; ni < 4; ++ni)
         acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[ni], fa[mi], acc[mi][ni], 0, 0, 0);
-    if constexpr (A_T && B_T) {
+    if constexpr (A_T && B_T && NMI == 8) {
       if (do_colsum) {
 #pragma unroll
         for (int mi = 0; mi < 8; ++mi)  // static register indices: the wave's pair is picked by a uniform compare
@@ -959,7 +971,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, int tile_m, int t
   }
   if (wave < 4) __builtin_amdgcn_s_barrier();  // balances the upper half's extra barrier
 
-  if constexpr (A_T && B_T) {
+  if constexpr (A_T && B_T && NMI == 8) {
     if (do_colsum && lane < 16) {  // lanes 0..15, register 0: the sums of columns 16 * mi + lane
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
@@ -973,13 +985,36 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, int tile_m, int t
   }
 
   if constexpr (!B_T) {
-    if (slab < 0 && m0 + XM <= p.M && n0 + XN <= p.N && full_epilogue_ok(p, sizeof(TOut) == 2)) {
-      write_wave_tile_full<TOut>(p, acc, m0 + wrow, n0 + wcol, lane, smem + SMEM_BYTES + wave * 2048);
+    if (slab < 0 && m0 + th <= p.M && n0 + XN <= p.N && full_epilogue_ok(p, sizeof(TOut) == 2)) {
+      write_wave_tile_full<TOut, NMI>(p, acc, m0 + wrow, n0 + wcol, lane, smem + SMEM_BYTES + wave * 2048);
       return;
     }
   }
-  write_tile<TOut, bf16_t, !B_T>(p, acc, m0 + wrow, n0 + wcol, lane, slab);
-  write_tile<TOut, bf16_t, !B_T>(p, acc + 4, m0 + wrow + 64, n0 + wcol, lane, slab);
+  const int row_end = min(p.M, m0 + th);
+  write_tile<TOut, bf16_t, !B_T, (NMI < 4 ? NMI : 4)>(p, acc, m0 + wrow, n0 + wcol, lane, slab, row_end);
+  if constexpr (NMI > 4)
+    write_tile<TOut, bf16_t, !B_T, NMI - 4>(p, acc + 4, m0 + wrow + 64, n0 + wcol, lane, slab, row_end);
+}
+
+// The block's tile: the lower wave half takes the first ceil(n / 2) of the tile's n = tile_h / 16 row groups, the
+// upper half the rest; each count is a compile-time constant of its own copy of the loop, so the accumulators
+// stay in registers under static indices.  Both copies execute the same sequence of barriers.
+template <bool A_T, bool B_T, typename TOut>
+__device__ __forceinline__ void gemm_tile(const GemmParams& p, int tile_m, int tile_n, int kbeg, int kend, int slab) {
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  if constexpr (A_T) {
+    gemm_tile_part<A_T, B_T, TOut, 8>(p, tile_m, tile_n, kbeg, kend, slab, wave, (wave >> 2) * 128, XM);
+  } else {
+    const int th = p.tile_h, n = th >> 4, nlo = (n + 1) >> 1;
+    const int mine = wave >= 4 ? n - nlo : nlo, wrow = wave >= 4 ? 16 * nlo : 0;
+    switch (mine) {
+      case 8: gemm_tile_part<A_T, B_T, TOut, 8>(p, tile_m, tile_n, kbeg, kend, slab, wave, wrow, th); break;
+      case 7: gemm_tile_part<A_T, B_T, TOut, 7>(p, tile_m, tile_n, kbeg, kend, slab, wave, wrow, th); break;
+      case 6: gemm_tile_part<A_T, B_T, TOut, 6>(p, tile_m, tile_n, kbeg, kend, slab, wave, wrow, th); break;
+      case 5: gemm_tile_part<A_T, B_T, TOut, 5>(p, tile_m, tile_n, kbeg, kend, slab, wave, wrow, th); break;
+      default: gemm_tile_part<A_T, B_T, TOut, 4>(p, tile_m, tile_n, kbeg, kend, slab, wave, wrow, th); break;
+    }
+  }
 }
 
 template <bool A_T, bool B_T, typename TOut>
@@ -1026,6 +1061,7 @@ __device__ __forceinline__ GemmParams params_of(const GroupDesc& d) {
   p.vec_c = (d.flags >> 1) & 1;
   p.alpha = 1.f;
   p.group = 1;
+  p.tile_h = XM;
   p.colsum = d.colsum;
   p.colsum_ws = d.ws ? d.ws + (int64_t)d.splits * d.M * d.N : nullptr;
   p.colsum_acc = (d.flags >> 2) & 1;
@@ -1273,7 +1309,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
     }
     __syncthreads();
   }
-  write_tile<float, float, false>(p, acc, m0 + wrow, n0 + wcol, lane, grid_slab());
+  write_tile<float, float, false>(p, acc, m0 + wrow, n0 + wcol, lane, grid_slab(), p.M);
 }
 }  // namespace f32
 
@@ -1526,9 +1562,31 @@ static int gemm_one(int layout, const void* A, const void* B, void* C, const voi
     use_big = false;
     use_staged = false;
   }
+  p.tile_h = b16x::XM;
   if (use_big) {
-    p.tiles_m = (int)((M + b16x::XM - 1) / b16x::XM);
     p.tiles_n = (int)((N + b16x::XN - 1) / b16x::XN);
+    // One block per CU: a launch takes whole rounds of the chip.  With a K-contiguous A the kernel can work on
+    // lower tiles, so pick the height (a multiple of 16) whose rounds cost least.  Measured at M = 25.6 k (256 ->
+    // 208 rows): a tile's time follows (rows + 256) rather than its rows (the B half of every K-step, the
+    // barriers and the fragment reads stay): K = 35000 NN -9 %, K = 2048 -5..-8 %, N = 1536 / 2048 with K = 512
+    // (three rounds and a bit -> three or four full ones) -3..-4 %; with K = 512 and one or two rounds the tile
+    // time is latency, not work, and more blocks were 3-7 % slower, so those keep 256 rows.  Not below 0.6 of a
+    // round of 256-tiles (split-K fills the chip there) nor from 16 rounds on (the last round's fill no longer
+    // matters).  SKHIP_GEMM_TILE_H forces a height.
+    const int64_t ncu = sk_num_cus(), t256 = ((M + 255) / 256) * p.tiles_n;
+    if (!a_t && 10 * t256 >= 6 * ncu && t256 < 16 * ncu) {
+      if (K >= 1024 || t256 > 2 * ncu) {
+        double best = 0;
+        for (int th = 256; th >= 144; th -= 16) {
+          const int64_t blocks = ((M + th - 1) / th) * p.tiles_n;
+          const double cost = (double)((blocks + ncu - 1) / ncu) * (th + 256);
+          if (th == 256 || cost < best) { best = cost; p.tile_h = th; }
+        }
+      }
+      const char* e = getenv("SKHIP_GEMM_TILE_H");
+      if (e && atoi(e) >= 144 && atoi(e) <= 256 && atoi(e) % 16 == 0) p.tile_h = atoi(e);
+    }
+    p.tiles_m = (int)((M + p.tile_h - 1) / p.tile_h);
   }
   const int bk = in_dtype == SK_BF16 ? (use_big ? b16x::BK : (fast && !use_staged) ? b16g::BK : b16::BK) : f32::BK;
   const int64_t tiles = (int64_t)p.tiles_m * p.tiles_n;

@@ -170,6 +170,57 @@ def test_gemm_bf16_row_cut(L):
     assert rel_err(out.cpu(), ref.cpu()) <= BF16_RTOL
 
 
+def test_gemm_bf16_tile_heights(L):
+    """The 256-tile kernel on lower tiles (tall products whose 256-row tiles would leave the chip's last round
+    partly empty): every height gives bit-for-bit the result of the 256-row tiles — plain, with the fused
+    epilogues, fp32 output, the NN form — and the plain product agrees with a float64 reference.  M is ragged
+    so the last tile of every height is cut by the matrix edge."""
+    import os
+    g = torch.Generator(device=DEV).manual_seed(41)
+    M, N, K = 25613, 512, 136
+    x = torch.randn((M, K), device=DEV, generator=g).to(torch.bfloat16)
+    W = torch.randn((N, K), device=DEV, generator=g).to(torch.bfloat16)
+    b = torch.randn(N, device=DEV, generator=g)
+    c0 = torch.randn((M, N), device=DEV, generator=g).to(torch.bfloat16)
+    Kn = 8200  # NN products take the 256-tile kernel from K = 8192
+    xn = torch.randn((M, Kn), device=DEV, generator=g).to(torch.bfloat16)
+    Wn = torch.randn((Kn, N), device=DEV, generator=g).to(torch.bfloat16)
+
+    def run():
+        out = {}
+        out["plain"] = L.gemm(L.GEMM_NT, x, W, M, N, K, K, K, split_k=False)
+        out["f32"] = L.gemm(L.GEMM_NT, x, W, M, N, K, K, K, out_dtype=torch.float32, split_k=False)
+        signs = torch.zeros((M, N // 16), dtype=torch.int16, device=DEV)
+        out["relu"] = L.gemm(L.GEMM_NT, x, W, M, N, K, K, K, bias=b, aux=signs, alpha=0.5,
+                             epilogue=L.EPI_RELU | L.EPI_RELU_BITS_OUT)
+        out["signs"] = signs
+        out["masked"] = L.gemm(L.GEMM_NT, x, W, M, N, K, K, K, aux=signs, epilogue=L.EPI_RELU_MASK_BITS)
+        acc = c0.clone()
+        L.gemm(L.GEMM_NT, x, W, M, N, K, K, K, out=acc, ldc=N, epilogue=L.EPI_ACCUM)
+        out["accum"] = acc
+        out["nn"] = L.gemm(L.GEMM_NN, xn, Wn, M, N, Kn, Kn, N, split_k=False)
+        return out
+
+    old = {k: os.environ.get(k) for k in ("SKHIP_GEMM_TILE_H", "SKHIP_GEMM_BIG")}
+    try:
+        os.environ["SKHIP_GEMM_BIG"] = "1"
+        os.environ["SKHIP_GEMM_TILE_H"] = "256"
+        ref = run()
+        rows = torch.arange(0, M, 97, device=DEV)
+        want = x[rows].double() @ W.double().t()
+        assert rel_err(ref["plain"][rows], want) <= BF16_RTOL
+        assert rel_err(ref["f32"][rows], want) <= 1e-5
+        assert rel_err(ref["nn"][rows], xn[rows].double() @ Wn.double()) <= BF16_RTOL
+        for th in (144, 160, 176, 192, 208, 224, 240, None):  # None: the library's own choice
+            os.environ.pop("SKHIP_GEMM_TILE_H", None) if th is None else os.environ.__setitem__("SKHIP_GEMM_TILE_H", str(th))
+            got = run()
+            for k in ref:
+                assert torch.equal(got[k], ref[k]), (th, k)
+    finally:
+        for k, v in old.items():
+            os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+
+
 @pytest.mark.parametrize("case", ["split_all", "full_round_and_tail", "many_problems"])
 def test_gemm_grouped_tn(L, case):
     """Grouped weight-gradient products: fewer tiles than CUs (everything K-split), a full round of
