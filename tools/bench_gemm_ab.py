@@ -39,6 +39,13 @@ SHAPES = [
 ]
 VARIANTS = [("small g1", {"SKHIP_GEMM_BIG": "0", "SKHIP_GEMM_GROUP": "1"}), ("small g8", {"SKHIP_GEMM_BIG": "0", "SKHIP_GEMM_GROUP": "8"}),
             ("big g1", {"SKHIP_GEMM_BIG": "1", "SKHIP_GEMM_GROUP": "1"}), ("big g8", {"SKHIP_GEMM_BIG": "1", "SKHIP_GEMM_GROUP": "8"})]
+# SK_AB_VARIANTS="name:ENV=1,ENV2=0;name2:-" replaces the variant list
+if os.environ.get("SK_AB_VARIANTS"):
+    VARIANTS = []
+    for a in os.environ["SK_AB_VARIANTS"].split(";"):
+        vname, _, envs = a.partition(":")
+        VARIANTS.append((vname, dict(kv.split("=") for kv in envs.split(",") if kv and kv != "-")))
+_keys = sorted({k for _, e in VARIANTS for k in e})
 only = sys.argv[1] if len(sys.argv) > 1 else ""
 dev = "cuda"
 g = torch.Generator(device=dev).manual_seed(0)
@@ -58,6 +65,8 @@ for name, layout, M, N, K, odt in SHAPES:
     errs = {}
     for rnd in range(5):
         for v, env in VARIANTS:
+            for k in _keys:
+                os.environ.pop(k, None)
             os.environ.update(env)
             if rnd == 0:
                 out.zero_()
