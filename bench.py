@@ -81,7 +81,9 @@ BATCHED_WGRADS = os.environ.get("SK_BENCH_BATCHED_WGRADS", "1") != "0"
 PACKED = True  # run the network on the batch without its padding rows (--padded turns it off)
 
 
-def train_step(m, opt, batch, reducer):
+def train_step(m, opt, batch, reducer, plans=None):
+    """One optimiser step.  `plans`: packing plans of this batch started a step earlier (Transformer.plan_ahead);
+    without them the step derives them itself and waits for the host copy."""
     from specialk_amd import ops
     src_seq, src_pos, tgt_seq, tgt_pos = batch
     if reducer is not None:
@@ -89,7 +91,7 @@ def train_step(m, opt, batch, reducer):
     else:
         opt.zero_grad()
     if PACKED:  # sentence lengths are derived from the ids on the device inside the timed step
-        pred, gold = m.forward_packed(src_seq, src_pos, tgt_seq, tgt_pos)
+        pred, gold = m.forward_packed(src_seq, src_pos, tgt_seq, tgt_pos, plans=plans)
         loss, stats = ops.xent(pred, gold, True, unit_grad=True)
     else:
         pred = m(src_seq, src_pos, tgt_seq, tgt_pos)
@@ -390,16 +392,24 @@ def main():
         batches.append(tuple(x.to(device) for x in (s, sp, t, tp)))
     tok_per_batch = [int((b[2][:, 1:] != PAD).sum()) for b in batches]
 
+    # Every step derives the packing plan (sentence lengths, row offsets; two small kernels and one host read) of the
+    # NEXT step's batch before it runs its own, as a loader prefetches: the host read then never stalls the queue.
+    def step(i, pending):
+        nxt = m.plan_ahead(*batches[(i + 1) % len(batches)]) if PACKED else None
+        train_step(m, opt, batches[i % len(batches)], reducer, plans=pending)
+        return nxt
+
+    pending = m.plan_ahead(*batches[0]) if PACKED else None
     for i in range(args.warmup):
-        train_step(m, opt, batches[i % len(batches)], reducer)
+        pending = step(i, pending)
     torch.cuda.synchronize()
     if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     tokens = 0
-    for i in range(args.steps):
-        train_step(m, opt, batches[i % len(batches)], reducer)
+    for i in range(args.warmup, args.warmup + args.steps):
+        pending = step(i, pending)
         tokens += tok_per_batch[i % len(batches)]
     torch.cuda.synchronize()
     if dist_on:

@@ -165,20 +165,35 @@ class TransformerModel(NMTModel):
             m.decoder.train(not o.freeze_decoder)
             m.generator.train(not o.freeze_decoder)
         totals = torch.zeros(3, dtype=torch.float64, device=self.device)
-        for batch in dataset:
-            shard = self._shard(batch)
-            # A rank whose shard of a short last batch is empty still has to join every
-            # collective: it runs sentence 0 with weight zero.
-            idle = shard[0].shape[0] == 0
-            if idle:
-                shard = tuple(x[:1] for x in batch)
-            src_seq, src_pos, tgt_seq, tgt_pos = (x.to(self.device, non_blocking=True) for x in shard)
+        want_packed = not (validation and o.log)
+
+        def staged():
+            """Batches one step ahead of their use: batch k + 1 is copied to the device and its packing plan
+            started (two small kernels, one host copy that nobody waits for yet) before batch k runs, so a step
+            begins without waiting for the device and the host keeps queueing work ahead of it."""
+            ahead = None
+            for batch in dataset:
+                shard = self._shard(batch)
+                # A rank whose shard of a short last batch is empty still has to join every
+                # collective: it runs sentence 0 with weight zero.
+                idle = shard[0].shape[0] == 0
+                if idle:
+                    shard = tuple(x[:1] for x in batch)
+                dev = tuple(x.to(self.device, non_blocking=True) for x in shard)
+                plans = m.plan_ahead(*dev) if self.packed and want_packed else None
+                if ahead is not None:
+                    yield ahead
+                ahead = (dev, idle, plans)
+            if ahead is not None:
+                yield ahead
+
+        for (src_seq, src_pos, tgt_seq, tgt_pos), idle, plans in staged():
             if not validation:
                 self.reducer.zero_grad() if self.reducer else self.optimiser.zero_grad()
             pred = None
-            if self.packed and not (validation and o.log):
+            if self.packed and want_packed:
                 try:  # the network on the batch without its padding rows: same loss, counts and gradients
-                    pred, gold = m.forward_packed(src_seq, src_pos, tgt_seq, tgt_pos)
+                    pred, gold = m.forward_packed(src_seq, src_pos, tgt_seq, tgt_pos, plans=plans)
                 except ValueError:  # not a right-padded batch
                     self.packed = False
             if pred is None:

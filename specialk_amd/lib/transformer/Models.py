@@ -69,12 +69,40 @@ class PackPlan:
         self.idx = idx[: self.n]
 
 
-def plan_packing(seqs, trims, check=None):
-    """PackPlans for right-padded id batches `seqs` (each (B, L) on the GPU), keeping the first
-    len_b - trim tokens of every sentence.  Lengths, offsets and row indices are computed on the
-    device (two small launches per batch); one device -> host copy fetches what the host must know
-    (row counts, longest sentence, whether the batches really are right-padded and, if `check` is
-    given, whether ids / positions fit their tables)."""
+class PendingPlans:
+    """Packing plans whose host-side facts (row counts, longest sentence, validity flags) are still on their way:
+    the device -> host copy was started without waiting.  `result()` waits for it (no wait at all if the copy was
+    started a step earlier, see Transformer.plan_ahead) and returns the PackPlans."""
+
+    def __init__(self, seqs, parts, facts_host, event, checked):
+        self.seqs, self.parts, self.facts_host, self.event, self.checked = seqs, parts, facts_host, event, checked
+        self._plans = None
+
+    def matches(self, *seqs):
+        return len(seqs) == len(self.seqs) and all(a is b for a, b in zip(seqs, self.seqs))
+
+    def result(self):
+        if self._plans is None:
+            self.event.synchronize()
+            facts = self.facts_host.tolist()
+            plans = []
+            for k, (seq, (off, idx)) in enumerate(zip(self.seqs, self.parts)):
+                ok, lo, mx, n = facts[4 * k:4 * k + 4]
+                if not ok or lo < 0:
+                    raise ValueError("packed execution needs right-padded batches whose sentences hold at least `trim` tokens")
+                plans.append(PackPlan(off, idx, seq.shape[0], seq.shape[1], mx, n))
+            if self.checked and not all(facts[4 * len(self.seqs):]):
+                raise IndexError("token id or position outside its embedding table")
+            self._plans = plans
+        return self._plans
+
+
+def plan_packing_async(seqs, trims, check=None):
+    """Starts the packing plans of right-padded id batches `seqs` (each (B, L) on the GPU), keeping the first
+    len_b - trim tokens of every sentence.  Lengths, offsets and row indices are computed on the device (two small
+    launches per batch); what the host must know (row counts, longest sentence, whether the batches really are
+    right-padded and, if `check` is given, whether ids / positions fit their tables) travels in ONE device -> host
+    copy into pinned memory that is not waited for here."""
     parts, facts = [], []
     for seq, trim in zip(seqs, trims):
         _, off, idx, f = _L.pack_plan(seq, trim, Constants.PAD)
@@ -82,16 +110,17 @@ def plan_packing(seqs, trims, check=None):
         facts.append(f)
     if check is not None:
         facts.append(torch.stack([(t.max() < limit).to(torch.int64) * (t.min() >= 0).to(torch.int64) for t, limit in check]))
-    facts = torch.cat(facts).cpu().tolist()
-    plans = []
-    for k, (seq, (off, idx)) in enumerate(zip(seqs, parts)):
-        ok, lo, mx, n = facts[4 * k:4 * k + 4]
-        if not ok or lo < 0:
-            raise ValueError("packed execution needs right-padded batches whose sentences hold at least `trim` tokens")
-        plans.append(PackPlan(off, idx, seq.shape[0], seq.shape[1], mx, n))
-    if check is not None and not all(facts[4 * len(seqs):]):
-        raise IndexError("token id or position outside its embedding table")
-    return plans
+    facts = torch.cat(facts)
+    host = torch.empty(facts.shape, dtype=facts.dtype, pin_memory=True)
+    host.copy_(facts, non_blocking=True)
+    event = torch.cuda.Event()
+    event.record()
+    return PendingPlans(list(seqs), parts, host, event, check is not None)
+
+
+def plan_packing(seqs, trims, check=None):
+    """PackPlans for `seqs` (see plan_packing_async), waiting for the one device -> host copy."""
+    return plan_packing_async(seqs, trims, check).result()
 
 
 class Encoder(nn.Module):
@@ -240,7 +269,18 @@ class Transformer(nn.Module):
         seq_logit = self.project(dec_output.reshape(B * Lt, d))
         return seq_logit.view(B, Lt, -1)
 
-    def forward_packed(self, src_seq, src_pos, tgt_seq, tgt_pos):
+    def plan_ahead(self, src_seq, src_pos, tgt_seq, tgt_pos):
+        """Starts the packing plans of a batch for forward_packed(..., plans=) without waiting for the host copy.
+        A training loop calls this for batch k + 1 before it runs batch k — as a loader prefetches — so that the
+        host never waits for the device at a step boundary and keeps queueing work ahead of it."""
+        check = None
+        if self.encoder.check_ids:
+            enc, dec = self.encoder, self.decoder
+            check = [(src_seq, enc.src_word_emb.num_embeddings), (src_pos, enc.position_enc.num_embeddings),
+                     (tgt_seq, dec.tgt_word_emb.num_embeddings), (tgt_pos, dec.position_enc.num_embeddings)]
+        return plan_packing_async([src_seq, tgt_seq], [0, 1], check)
+
+    def forward_packed(self, src_seq, src_pos, tgt_seq, tgt_pos, plans=None):
         """Training-time fast path: the same network on the batch WITHOUT its padding.
 
         Returns (logits (n, V), gold (n,)) for the n non-pad target positions, sentence after sentence —
@@ -249,13 +289,11 @@ class Transformer(nn.Module):
         Each sentence's last target token is never an input (forward drops it for the longest
         sentence; for shorter ones its row predicts PAD, is ignored by the loss and — the decoder
         being causal — seen by no other row), so packed target rows are tokens 0 .. len-2.
-        Requires right-padded batches (what collate_fn builds); raises ValueError otherwise."""
-        check = None
-        if self.encoder.check_ids:
-            enc, dec = self.encoder, self.decoder
-            check = [(src_seq, enc.src_word_emb.num_embeddings), (src_pos, enc.position_enc.num_embeddings),
-                     (tgt_seq, dec.tgt_word_emb.num_embeddings), (tgt_pos, dec.position_enc.num_embeddings)]
-        src_plan, tgt_plan = plan_packing([src_seq, tgt_seq], [0, 1], check)
+        Requires right-padded batches (what collate_fn builds); raises ValueError otherwise.
+        `plans`: the result of plan_ahead() for these very tensors (ignored otherwise)."""
+        if plans is None or not plans.matches(src_seq, tgt_seq):
+            plans = self.plan_ahead(src_seq, src_pos, tgt_seq, tgt_pos)
+        src_plan, tgt_plan = plans.result()
         enc_packed = self.encoder.forward_packed(src_seq, src_pos, src_plan)
         dec_packed = self.decoder.forward_packed(tgt_seq, tgt_pos, tgt_plan, enc_packed, src_plan)
         gold = tgt_seq.reshape(-1)[tgt_plan.idx + 1]
