@@ -53,12 +53,12 @@ class DecoderLayer(nn.Module):
         self.pos_ffn = PositionwiseFeedForward(d_model, d_inner, dropout=dropout)
 
     def forward_2d(self, x, enc, B, Lt, Ls, key_pad=None, src_key_pad=None, causal=True, slf_dense=None,
-                   cross_dense=None, row_pad=None, want_attn=False, off=None, src_off=None):
+                   cross_dense=None, row_pad=None, want_attn=False, off=None, src_off=None, kv_pre=None):
         x, a1 = self.slf_attn.forward_2d(x, x, B, Lt, Lt, key_pad=key_pad, causal=causal, dense_mask=slf_dense,
                                          row_pad=row_pad, want_attn=want_attn, self_attn=True, q_off=off, k_off=off)
         x, a2 = self.enc_attn.forward_2d(x, enc, B, Lt, Ls, key_pad=src_key_pad, dense_mask=cross_dense,
                                          row_pad=row_pad, want_attn=want_attn, self_attn=False, q_off=off,
-                                         k_off=src_off)
+                                         k_off=src_off, kv_pre=kv_pre)
         x = self.pos_ffn.forward_2d(x, row_pad=row_pad)
         return x, a1, a2
 

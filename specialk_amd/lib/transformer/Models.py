@@ -194,9 +194,12 @@ class Decoder(nn.Module):
         if enc2d.dtype != self.compute_dtype:
             enc2d = enc2d.to(self.compute_dtype)
         slf_attns, enc_attns = [], []
-        for layer in self.layer_stack:
-            x, a1, a2 = layer.forward_2d(x, enc2d, B, Lt, Ls, key_pad=key_pad, src_key_pad=src_key_pad, causal=True,
-                                         row_pad=key_pad.view(-1), want_attn=return_attns)
+        # the k | v projections of the encoder output for all layers in one product
+        kv_all, pres = ops.cross_kv(enc2d, [layer.enc_attn for layer in self.layer_stack])
+        for li, layer in enumerate(self.layer_stack):
+            x, a1, a2 = layer.forward_2d(x, enc2d if kv_all is None else kv_all, B, Lt, Ls, key_pad=key_pad,
+                                         src_key_pad=src_key_pad, causal=True, row_pad=key_pad.view(-1),
+                                         want_attn=return_attns, kv_pre=None if kv_all is None else pres[li])
             if return_attns:
                 slf_attns += [a1]
                 enc_attns += [a2]
@@ -211,9 +214,11 @@ class Decoder(nn.Module):
         flat = plan.idx
         x = ops.EmbedFn.apply(tgt_seq.reshape(-1)[flat], tgt_pos.reshape(-1)[flat], self.tgt_word_emb.weight,
                               self.position_enc.weight, self.compute_dtype)
-        for layer in self.layer_stack:
-            x, _, _ = layer.forward_2d(x, enc_packed, plan.B, plan.max_len, src_plan.max_len, causal=True,
-                                       off=plan.off, src_off=src_plan.off)
+        kv_all, pres = ops.cross_kv(enc_packed, [layer.enc_attn for layer in self.layer_stack])
+        for li, layer in enumerate(self.layer_stack):
+            x, _, _ = layer.forward_2d(x, enc_packed if kv_all is None else kv_all, plan.B, plan.max_len,
+                                       src_plan.max_len, causal=True, off=plan.off, src_off=src_plan.off,
+                                       kv_pre=None if kv_all is None else pres[li])
         return x
 
 

@@ -34,16 +34,17 @@ class MultiHeadAttention(nn.Module):
 
     # -- fast path used by the encoder / decoder stacks
     def forward_2d(self, q_in, kv_in, B, Lq, Lk, key_pad=None, causal=False, dense_mask=None, row_pad=None,
-                   want_attn=False, self_attn=None, q_off=None, k_off=None):
+                   want_attn=False, self_attn=None, q_off=None, k_off=None, kv_pre=None):
         """q_in (B*Lq, d), kv_in (B*Lk, d) -> (LayerNorm(fc(attn) + q_in) with pad rows zeroed, attn|None).
         With q_off / k_off (int32 [B+1] row offsets) the inputs are packed token rows and Lq / Lk the
-        longest sequences."""
+        longest sequences.  kv_pre: kv_in holds the k | v projections of all decoder layers already
+        (ops.cross_kv) and kv_pre names this layer's columns."""
         training = self.training
         cfg = dict(B=B, Lq=Lq, Lk=Lk, H=self.n_head, dk=self.d_k, dv=self.d_v, q_off=q_off, k_off=k_off,
                    self_attn=(q_in is kv_in) if self_attn is None else self_attn,
                    key_pad=key_pad, causal=bool(causal), dense_mask=dense_mask,
                    scale=1.0 / float(self.attention.temperature),
-                   p_attn=self.attention.dropout.p if training else 0.0, want_attn=want_attn)
+                   p_attn=self.attention.dropout.p if training else 0.0, want_attn=want_attn, kv_pre=kv_pre)
         out, attn = ops.MHAFn.apply(q_in, kv_in, self.w_qs.weight, self.w_qs.bias, self.w_ks.weight, self.w_ks.bias,
                                     self.w_vs.weight, self.w_vs.bias, self.fc.weight, self.fc.bias, cfg)
         y = ops.add_ln(out, q_in, self.layer_norm.weight, self.layer_norm.bias, row_pad, self.layer_norm.eps,

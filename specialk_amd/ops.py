@@ -495,6 +495,13 @@ class MHAFn(torch.autograd.Function):
             ldq = ldk = ldv = qkv.stride(0)
             Q, K, V = qkv[:, :nq], qkv[:, nq:nq + nk], qkv[:, nq + nk:]
             _project(q_in, (Wq, Wk, Wv), (bq, bk, bv), qkv, ldq, dt)
+        elif cfg.get("kv_pre") is not None:
+            # kv_in holds the k | v projections of every decoder layer (CrossKVFn); this layer's are a column slice
+            c0 = cfg["kv_pre"].col
+            Q = torch.empty((Tq, nq), dtype=dt, device=dev)
+            K, V = kv_in[:, c0:c0 + nk], kv_in[:, c0 + nk:c0 + nk + nv]
+            ldq, ldk, ldv = nq, kv_in.stride(0), kv_in.stride(0)
+            _project(q_in, (Wq,), (bq,), Q, ldq, dt)
         else:
             Q = torch.empty((Tq, nq), dtype=dt, device=dev)
             kv = torch.empty((Tk, nk + nv), dtype=dt, device=dev)
@@ -540,6 +547,15 @@ class MHAFn(torch.autograd.Function):
             dqkv = torch.empty((Tq, nq + nk + nv), dtype=dt, device=dev)
             dQ, dK, dV = dqkv[:, :nq], dqkv[:, nq:nq + nk], dqkv[:, nq + nk:]
             lddq = lddk = lddv = dqkv.stride(0)
+        elif cfg.get("kv_pre") is not None:
+            # the key / value gradients of all layers share one buffer, which CrossKVFn.backward turns into the
+            # encoder-output gradient and the k / v weight gradients once every layer has written its slice
+            pre = cfg["kv_pre"]
+            dkv_all = pre.shared.grad_buffer(kv_in)
+            dQ = torch.empty((Tq, nq), dtype=dt, device=dev)
+            dK, dV = dkv_all[:, pre.col:pre.col + nk], dkv_all[:, pre.col + nk:pre.col + nk + nv]
+            lddq, lddk, lddv = nq, dkv_all.stride(0), dkv_all.stride(0)
+            pre.shared.written.add(pre.col)
         else:
             dQ = torch.empty((Tq, nq), dtype=dt, device=dev)
             dkv = torch.empty((Tk, nk + nv), dtype=dt, device=dev)
@@ -553,6 +569,10 @@ class MHAFn(torch.autograd.Function):
         # launch (bf16 inside batched_weight_grads()): one problem per parameter, each written straight into its
         # .grad together with its bias gradient.  Otherwise one product and one column sum over the widest buffer
         # that shares an input ([dq|dk|dv] for self-attention, [dk|dv] otherwise).
+        if cfg.get("kv_pre") is not None:  # k / v weights and the encoder output get their gradients from CrossKVFn
+            dWq, dbq = _weight_grad(dQ, q_in, Wq, Tq, need[2], bias=bq if need[3] else None)
+            dq_in = _input_grad(dQ, lddq, (Wq,), Tq, d, dt, add_to=dres)  # accumulates into dres in place
+            return dq_in, None, dWq, dbq, None, None, None, None, dWo, dbo, None
         kv_src = q_in if cfg["self_attn"] else kv_in
         batched = dt == torch.bfloat16 and _batchable(dQ, q_in) and _batchable(dK, kv_src) and _batchable(dV, kv_src)
         if batched:
@@ -578,6 +598,98 @@ class MHAFn(torch.autograd.Function):
             dq_in = _input_grad(dQ, lddq, (Wq,), Tq, d, dt, add_to=dres)  # accumulates into dres in place
             dkv_in = _input_grad(dkv, lddk, (Wk, Wv), Tk, d, dt)
         return dq_in, dkv_in, dWq, dbq, dWk, dbk, dWv, dbv, dWo, dbo, None
+
+
+class CrossKVShared:
+    """What the decoder layers of one forward pass share about their hoisted key / value projections: the buffer
+    their backward passes write the key / value gradients into, and which column blocks have been written."""
+
+    def __init__(self):
+        self.dkv, self.written = None, set()
+
+    def grad_buffer(self, kv_all):
+        if self.dkv is None:
+            self.dkv = torch.empty(kv_all.shape, dtype=kv_all.dtype, device=kv_all.device)
+        return self.dkv
+
+
+class CrossKVPre:
+    """A decoder layer's handle on the hoisted projections: its column offset in the shared buffers."""
+
+    def __init__(self, shared, col):
+        self.shared, self.col = shared, col
+
+
+class CrossKVFn(torch.autograd.Function):
+    """The key | value projections of the encoder output for ALL decoder layers as one product
+    (lib/transformer/SubLayers.py:47-48 applied by every DecoderLayer.enc_attn to the same enc_output,
+    lib/transformer/Layers.py:50-52): (T_src, d) x [Wk_0; Wv_0; Wk_1; ...]^T -> (T_src, sum n_i), each layer reading
+    its column block in place.  Backward runs once, after every layer has left its key / value gradients in the
+    shared buffer (they reach it directly, not through autograd, which would add full-width tensors layer by
+    layer): one long-K product for the encoder-output gradient instead of one short product and one addition per
+    layer, and the weight / bias gradients per parameter (queued for the grouped launch where that is on).
+    params: Wk_0, bk_0, Wv_0, bv_0, Wk_1, ..."""
+
+    @staticmethod
+    def forward(ctx, enc, shared, *params):
+        Ws, bs = params[0::2], params[1::2]
+        Tk = enc.shape[0]
+        n_tot = sum(_as2d(w)[0] for w in Ws)
+        kv = torch.empty((Tk, n_tot), dtype=enc.dtype, device=enc.device)
+        _project(enc, Ws, bs, kv, n_tot, enc.dtype)
+        ctx.save_for_backward(enc, *params)
+        ctx.shared = shared
+        ctx.set_materialize_grads(False)
+        return kv
+
+    @staticmethod
+    def backward(ctx, dkv_direct):
+        enc, *params = ctx.saved_tensors
+        Ws, bs = params[0::2], params[1::2]
+        shared, need = ctx.shared, ctx.needs_input_grad
+        Tk, d = enc.shape
+        dt = enc.dtype
+        n_tot = sum(_as2d(w)[0] for w in Ws)
+        dkv = shared.dkv
+        shared.dkv = None
+        if dkv is None and dkv_direct is None:
+            return (None,) * (2 + len(params))
+        if dkv is None:
+            dkv = dkv_direct.contiguous()
+        else:
+            # column blocks no layer wrote (a layer outside the differentiated graph) carry no gradient
+            off = 0
+            for i in range(0, len(Ws), 2):
+                n = _as2d(Ws[i])[0] + _as2d(Ws[i + 1])[0]
+                if off not in shared.written:
+                    dkv[:, off:off + n].zero_()
+                off += n
+            if dkv_direct is not None:  # the projections were also used through autograd
+                dkv = dkv + dkv_direct
+        shared.written = set()
+        d_enc = _input_grad(dkv, n_tot, Ws, Tk, d, dt) if need[0] else None
+        grads, off = [], 0
+        for i, (W, b) in enumerate(zip(Ws, bs)):
+            n = _as2d(W)[0]
+            blk = dkv[:, off:off + n]
+            nW, nb = need[2 + 2 * i], need[3 + 2 * i]
+            dW, db = _weight_grad(blk, enc, W, Tk, nW, bias=b if nb else None)
+            grads += [dW, db]
+            off += n
+        return (d_enc, None, *grads)
+
+
+def cross_kv(enc, attns):
+    """(kv_all, [CrossKVPre per attention module]) for the encoder-decoder attention modules `attns` of a decoder
+    stack, or (None, None) when SK_CROSS_KV_HOIST=0 asks for one projection per layer."""
+    if os.environ.get("SK_CROSS_KV_HOIST", "1") == "0" or len(attns) < 2:
+        return None, None
+    shared, params, pres, col = CrossKVShared(), [], [], 0
+    for a in attns:
+        params += [a.w_ks.weight, a.w_ks.bias, a.w_vs.weight, a.w_vs.bias]
+        pres.append(CrossKVPre(shared, col))
+        col += a.w_ks.weight.shape[0] + a.w_vs.weight.shape[0]
+    return CrossKVFn.apply(enc, shared, *params), pres
 
 
 class SDPAFn(torch.autograd.Function):
