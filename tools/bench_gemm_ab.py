@@ -30,6 +30,7 @@ SHAPES = [
     ("packed NT 25472x1024x512", 0, 25472, 2 * d, d, torch.bfloat16),
     ("packed NT 25472x512x1536", 0, 25472, d, 3 * d, torch.bfloat16),
     ("cube NT 8192x8192x8192", 0, 8192, 8192, 8192, torch.bfloat16),
+    ("cube NT 4096x4096x4096", 0, 4096, 4096, 4096, torch.bfloat16),
     ("dgrad NN T x512 x512", 1, T, d, d, torch.bfloat16),
     ("dgrad NN T x2048x512", 1, T, F, d, torch.bfloat16),
     ("dgrad NN T x512 x2048", 1, T, d, F, torch.bfloat16),
