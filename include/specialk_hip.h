@@ -59,6 +59,15 @@ const char* skhip_last_error(void);
  * touch the runtime on the hot path.  Every entry point calls it lazily.                */
 int skhip_init(void);
 
+/* ---- CUs held by other work --------------------------------------------------------------
+ * No counterpart in the reference (nn.DataParallel, train.py:385-388, has no notion of it): the large-tile GEMMs
+ * run one workgroup per CU and size their tiles so that a launch fills whole rounds of the chip.  When another
+ * kernel holds CUs for as long as they run — RCCL's all-reduce kernels during the backward pass of a data-parallel
+ * step — a launch planned for all CUs needs a second, almost empty round.  n = the CUs to leave out of that
+ * planning (0 = none, the default; SKHIP_RESERVE_CUS sets the start value).  Affects scheduling only, never
+ * results.  Not thread-safe against concurrent GEMM calls.                                                    */
+int skhip_set_reserved_cus(int n);
+
 /* ---- GEMM ---------------------------------------------------------------------------
  * Replaces: nn.Linear w_qs/w_ks/w_vs/fc (lib/transformer/SubLayers.py:46-48,62), the
  * Conv1d(k=1) pair of the FFN (SubLayers.py:73-74,81), the generator projection

@@ -24,7 +24,7 @@ EXPORTS = [
     "skhip_embed_bwd", "skhip_pack_plan", "skhip_xent_fwd_bwd", "skhip_adam_multi", "skhip_cast_multi", "skhip_cast2d_multi", "skhip_convert",
     "skhip_decode_attn", "skhip_beam_topk_ws_bytes", "skhip_beam_topk", "skhip_beam_update", "skhip_gather_rows",
     "skhip_decode_stack_ws_bytes", "skhip_decode_stack", "skhip_beam_topk_stats",
-    "skhip_softmax_rows", "skhip_conv_windows", "skhip_cnn_head", "skhip_collate",
+    "skhip_softmax_rows", "skhip_conv_windows", "skhip_cnn_head", "skhip_collate", "skhip_set_reserved_cus",
 ]
 
 _lib = None
@@ -87,6 +87,11 @@ def load():
 
 def version():
     return load().skhip_version().decode()
+
+
+def set_reserved_cus(n):
+    """CUs the large-tile GEMMs leave out of their round planning (held by communication kernels meanwhile)."""
+    _check(load().skhip_set_reserved_cus(int(n)), "skhip_set_reserved_cus")
 
 
 def _check(rc, what):

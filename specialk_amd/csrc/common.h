@@ -16,6 +16,7 @@ typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 // ------------------------------------------------------------------ error handling
 void sk_set_error(const char* fmt, ...);
 int sk_num_cus();
+int sk_sched_cus();  // CUs the GEMM schedulers plan for (sk_num_cus() minus the reserved ones)
 int sk_colsum_scratch(float** ptr);  // gemm.hip: device address of the built-in column-sum scratch
 
 #define SK_CHECK_ARG(cond, ...)        \

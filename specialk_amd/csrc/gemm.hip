@@ -1430,7 +1430,7 @@ extern "C" int skhip_gemm(int layout, const void* A, const void* B, void* C, con
       M > 0 && N > 0 &&
       M < (1ll << 31) && N < (1ll << 31) && !(epilogue & (SK_EPI_RELU_BITS_OUT | SK_EPI_RELU_MASK_BITS)) &&
       !(env_cut && env_cut[0] == '0')) {
-    const int64_t tm = (M + 255) / 256, tn = (N + 255) / 256, ncu = sk_num_cus();
+    const int64_t tm = (M + 255) / 256, tn = (N + 255) / 256, ncu = sk_sched_cus();
     const int64_t t256 = tm * tn, rounds = t256 / ncu, tail = t256 % ncu;
     if (rounds >= 1 && rounds < 8 && tail > 0 && 2 * tail < ncu) {
       const int64_t rows_full = rounds * ncu / tn;  // whole tile rows inside the full rounds
@@ -1539,7 +1539,7 @@ static int gemm_one(int layout, const void* A, const void* B, void* C, const voi
   // (1060 vs 1290 us: the 512-byte weight rows load in longer pieces); for K <= 2048 NT stays ahead.
   const bool nn_long = layout == SK_GEMM_NN && K >= 8192;
   if (in_dtype == SK_BF16 && fast && ((layout == SK_GEMM_NT && !use_staged) || (nn_long && !(env_staged && env_staged[0] == '1')))) {
-    const int64_t t256 = ((M + 255) / 256) * ((N + 255) / 256), ncu = sk_num_cus();
+    const int64_t t256 = ((M + 255) / 256) * ((N + 255) / 256), ncu = sk_sched_cus();
     const int64_t rounds = (t256 + ncu - 1) / ncu;
     const double fill = (double)t256 / (double)(rounds * ncu);
     use_big = t256 >= 8 * ncu || (K >= 1024 && fill >= 0.7) || (rounds == 1 && fill >= 0.7);
@@ -1573,7 +1573,7 @@ static int gemm_one(int layout, const void* A, const void* B, void* C, const voi
     // time is latency, not work, and more blocks were 3-7 % slower, so those keep 256 rows.  Not below 0.6 of a
     // round of 256-tiles (split-K fills the chip there) nor from 16 rounds on (the last round's fill no longer
     // matters).  SKHIP_GEMM_TILE_H forces a height.
-    const int64_t ncu = sk_num_cus(), t256 = ((M + 255) / 256) * p.tiles_n;
+    const int64_t ncu = sk_sched_cus(), t256 = ((M + 255) / 256) * p.tiles_n;
     if (!a_t && 10 * t256 >= 6 * ncu && t256 < 16 * ncu) {
       if (K >= 1024 || t256 > 2 * ncu) {
         double best = 0;
@@ -1593,7 +1593,7 @@ static int gemm_one(int layout, const void* A, const void* B, void* C, const voi
   SK_CHECK_ARG(tiles < (1ll << 31), "skhip_gemm: too many tiles");
   // deterministic split-K when the output alone cannot fill the chip
   int splits = 1;
-  const int cus = sk_num_cus();
+  const int cus = sk_sched_cus();
   if (workspace && tiles < cus && K >= 8 * bk) {
     // as many splits as fill the resident block slots of the chosen kernel WITHOUT spilling into a
     // further, mostly empty round (48 tiles x 11 splits on 512 slots ran 3 rounds instead of 2)
@@ -1708,7 +1708,7 @@ extern "C" int skhip_gemm_grouped_tn(const int64_t* problems, int n, void* works
   hipStream_t stream = (hipStream_t)stream_;
   SK_CHECK_ARG(n >= 0 && (n == 0 || problems), "skhip_gemm_grouped_tn: bad problem table");
   if (n == 0) return SK_OK;
-  const int ncu = sk_num_cus();
+  const int ncu = sk_sched_cus();
   int64_t total_tiles = 0;
   for (int i = 0; i < n; ++i) {
     const int64_t* q = problems + kProblemFields * i;
@@ -1850,7 +1850,7 @@ extern "C" int skhip_colsum(const void* X, float* out, int64_t M, int64_t N, int
   const bool vec = ((uintptr_t)X % 16 == 0) && (ldx % vn == 0) && (N % vn == 0);
   int col_groups = vec ? (int)((N + 16 * vn - 1) / (16 * vn)) : (int)((N + 63) / 64);
   int chunks = 1;
-  const int cus = sk_num_cus();
+  const int cus = sk_sched_cus();
   while (col_groups * chunks < 4 * cus && chunks < 128 && M / (chunks * 2) >= 64) chunks *= 2;
   while (chunks > 1 && (!partial || (int64_t)chunks * N * 4 > workspace_bytes)) chunks /= 2;
   int rows_per_block = (int)((M + chunks - 1) / chunks);

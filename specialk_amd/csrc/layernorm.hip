@@ -281,16 +281,19 @@ int check_d(const char* who, int d, int dtype) {
   return SK_OK;
 }
 
-// Blocks of 256 threads of `kernel` that are resident on the whole chip at once (cached per kernel).
+// Blocks of 256 threads of `kernel` that are resident at once on the CUs no other work holds (blocks per CU
+// cached per kernel): a grid of exactly one resident round whose blocks share the rows evenly takes twice as long
+// if even a few of its blocks have to wait for a CU.
 int64_t resident_blocks(const void* kernel, size_t smem) {
   static std::mutex mu;
   static std::map<const void*, int64_t> cache;
   std::lock_guard<std::mutex> lock(mu);
   auto it = cache.find(kernel);
-  if (it != cache.end()) return it->second;
+  if (it != cache.end()) return it->second * sk_sched_cus();
   int per_cu = 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, smem) != hipSuccess || per_cu < 1) per_cu = 1;
-  return cache[kernel] = (int64_t)per_cu * sk_num_cus();
+  cache[kernel] = per_cu;
+  return (int64_t)per_cu * sk_sched_cus();
 }
 
 }  // namespace

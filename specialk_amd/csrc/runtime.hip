@@ -1,6 +1,7 @@
 // Library-wide state: last-error string (thread local) and cached device properties.
 #include "common.h"
 #include <mutex>
+#include <stdlib.h>
 
 static thread_local char g_err[512] = "";
 static int g_num_cus = 0;
@@ -24,6 +25,28 @@ static void query_device() {
 int sk_num_cus() {
   std::call_once(g_once, query_device);
   return g_num_cus;
+}
+
+// CUs the GEMM schedulers plan their rounds for: all of them, minus those the caller has said are held by other
+// work while the GEMMs run (skhip_set_reserved_cus; SKHIP_RESERVE_CUS as the start value).
+static int g_reserved_cus = -1;
+int sk_sched_cus() {
+  if (g_reserved_cus < 0) {
+    const char* e = getenv("SKHIP_RESERVE_CUS");
+    const int v = e ? atoi(e) : 0;
+    g_reserved_cus = v > 0 ? v : 0;
+  }
+  const int n = sk_num_cus() - g_reserved_cus;
+  return n >= 8 ? n : 8;
+}
+
+extern "C" int skhip_set_reserved_cus(int n) {
+  if (n < 0 || n > sk_num_cus() - 8) {
+    sk_set_error("skhip_set_reserved_cus: %d not in 0..%d", n, sk_num_cus() - 8);
+    return SK_ERR_ARG;
+  }
+  g_reserved_cus = n;
+  return SK_OK;
 }
 
 extern "C" int skhip_init(void) {

@@ -367,11 +367,11 @@ __global__ __launch_bounds__(256, (NV <= 8 ? 4 : NV <= 20 ? 3 : 2)) void xent_ro
   }
 }
 
-// Blocks of `kernel` (256 threads, no dynamic LDS) resident on the chip at once.
-int64_t xent_resident_blocks(const void* kernel) {
+// Blocks of `kernel` (256 threads, no dynamic LDS) resident on one CU at once.
+int64_t xent_blocks_per_cu(const void* kernel) {
   int per_cu = 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, 0) != hipSuccess || per_cu < 1) per_cu = 1;
-  return (int64_t)per_cu * sk_num_cus();
+  return per_cu;
 }
 
 }  // namespace
@@ -392,8 +392,9 @@ extern "C" int skhip_xent_fwd_bwd(const void* logits, const int64_t* gold, void*
   if (dtype == SK_BF16 && vec_ok && V >= 4096 && V <= 24 * 2048 && logit_scale > 0.f && !(env_rr && env_rr[0] == '0')) {
 #define XENT_RR(NV)                                                                                              \
   do {                                                                                                           \
-    static int64_t cap = 0;                                                                                      \
-    if (!cap) cap = xent_resident_blocks((const void*)xent_rowreg_kernel<NV>);                                   \
+    static int64_t per_cu = 0;                                                                                   \
+    if (!per_cu) per_cu = xent_blocks_per_cu((const void*)xent_rowreg_kernel<NV>);                               \
+    const int64_t cap = per_cu * sk_sched_cus(); /* one resident round on the CUs no other work holds */         \
     const int64_t nb = T < cap ? T : cap;                                                                        \
     hipLaunchKernelGGL((xent_rowreg_kernel<NV>), dim3((unsigned)nb), dim3(256), 0, stream, (const bf16_t*)logits, \
                        gold, (bf16_t*)dlogits, out_stats, T, (int)V, ldl, logit_scale, smoothing_eps, pad_id,    \
