@@ -79,11 +79,13 @@ __device__ __forceinline__ void team_sync(TeamCtx& c) {
   __syncthreads();
   c.count += 1;
   if (threadIdx.x == 0 && !c.dead) {
-    __hip_atomic_fetch_add(c.flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int target = TEAM * c.count;
+    // the value the increment returns already tells the last arriver that everybody is here: no poll for it
+    int seen = __hip_atomic_fetch_add(c.flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
     int spins = 0;
-    while (__hip_atomic_load(c.flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+    while (seen < target) {
       __builtin_amdgcn_s_sleep(1);
+      seen = __hip_atomic_load(c.flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (++spins > SPIN_LIMIT) {
         __hip_atomic_store(c.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         c.dead = true;
