@@ -967,3 +967,44 @@ def test_full_size_weight_gradients_layernorm_and_adam(L):
     for p, rp, c in zip(ps, ref_p, copies):
         assert rel_err(p, rp) <= 1e-6
         assert torch.equal(c, p.to(torch.bfloat16))
+
+
+def test_reserved_cus_change_scheduling_not_results(L):
+    """skhip_set_reserved_cus: CUs left out of the GEMMs' round planning (held by communication kernels meanwhile)
+    change tile heights, K splits and grid sizes — not the values: LayerNorm and the loss kernel bit for bit against
+    the unreserved run; the products, whose number of K splits follows the CU count when their tiles do not fill the
+    chip, to fp32 summation-order noise (one bf16 rounding step for bf16 outputs); argument errors."""
+    g = torch.Generator().manual_seed(21)
+    M = 6000
+    x, w1, w2 = rnd((M, 512), torch.bfloat16, g).to(DEV), rnd((512, 512), torch.bfloat16, g).to(DEV), rnd((2048, 512), torch.bfloat16, g).to(DEV)
+    dy = rnd((M, 2048), torch.bfloat16, g).to(DEV)
+    res = rnd((M, 512), torch.bfloat16, g).to(DEV)
+    gamma, beta = torch.ones(512, device=DEV), torch.zeros(512, device=DEV)
+    logits = rnd((700, 4096), torch.bfloat16, g).to(DEV)
+    gold = torch.randint(1, 4096, (700,), generator=g).to(DEV)
+
+    def run():
+        out = [L.gemm(L.GEMM_NT, x, w1, M, 512, 512, 512, 512), L.gemm(L.GEMM_NT, x, w2, M, 2048, 512, 512, 512),
+               L.gemm(L.GEMM_TN, dy, x, 2048, 512, M, 2048, 512, out_dtype=torch.float32)]
+        gw = torch.zeros((2048, 512), dtype=torch.float32, device=DEV)
+        gb = torch.zeros(2048, dtype=torch.float32, device=DEV)
+        L.gemm_grouped_tn([(dy, x, gw, 2048, 512, M, 2048, 512, 512, False, gb, False)])
+        out += [gw, gb, L.add_ln_fwd(x, res, gamma, beta, None, 1e-5, 0.1, 7)[0]]
+        dl, stats = torch.empty_like(logits), torch.zeros(3, dtype=torch.float64, device=DEV)
+        L.xent_fwd_bwd(logits, gold, dl, stats, 1.0, 0.1, 0)
+        return out + [dl, stats]
+
+    try:
+        ref = run()
+        for n in (8, 40, 200):
+            L.set_reserved_cus(n)
+            for i, (a, b) in enumerate(zip(run(), ref)):
+                if i < 5:   # products: the number of K splits follows the CU count (bf16 outputs: one rounding step)
+                    assert rel_err(a, b.double()) <= (5e-3 if a.dtype == torch.bfloat16 else 1e-5), (n, i)
+                else:
+                    assert torch.equal(a, b), (n, i)
+        for bad in (-1, 10 ** 6):
+            with pytest.raises(RuntimeError):
+                L.set_reserved_cus(bad)
+    finally:
+        L.set_reserved_cus(0)
