@@ -24,6 +24,8 @@ NOT zeroed (392 MB per step for the base model): the first producer of a gradien
     copied into it by one multi-tensor copy, after which .grad is the bucket view again.
   * A parameter that got no gradient in a step has its slice zeroed in finish(), before the bucket is reduced.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -63,6 +65,12 @@ class GradBucketReducer:
         self._bucket_of = {p.data_ptr(): bi for bi, (_, plist) in enumerate(self.buckets) for p in plist}
         self._views, self._claimed = {}, set()
         self.gathered_matrix_bytes = 0  # diagnostics: matrix gradients that took the copy instead of a direct write
+        # SK_DP_RESERVE_CUS=n: from a step's first all-reduce until finish() the large-tile GEMMs plan their rounds
+        # for n CUs fewer (skhip_set_reserved_cus): RCCL's kernels hold CUs meanwhile, and a launch planned for all
+        # of them then needs an extra, almost empty round.  0 (default): off — how many CUs RCCL takes has to be
+        # measured on a multi-GPU node.
+        self.reserve_cus = int(os.environ.get("SK_DP_RESERVE_CUS", "0"))
+        self._reserved = False
         for flat, plist in self.buckets:
             off = 0
             for p in plist:
@@ -105,8 +113,15 @@ class GradBucketReducer:
             if self._pending[bi] == 0:
                 flat = self.buckets[bi][0]
                 self._gather_late(bi)
+                self._reserve(True)
                 self._handles.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         return hook
+
+    def _reserve(self, on):
+        if self.reserve_cus > 0 and on != self._reserved:
+            from . import _lib
+            _lib.set_reserved_cus(self.reserve_cus if on else 0)
+            self._reserved = on
 
     def bucket_view(self, p):
         """The slice of its bucket that holds the gradient of p, for producers that write a gradient in place
@@ -184,6 +199,7 @@ class GradBucketReducer:
                     self._pending[bi] = 0
             for h in self._handles:
                 h.wait()
+            self._reserve(False)
         if self.active:  # every .grad is the bucket view again (parameters without a gradient read as zero)
             for flat, plist in self.buckets:
                 off = 0
