@@ -56,6 +56,7 @@ struct StackArgs {
   float* zbuf;      // [R32][512]
   float* pbuf;      // [8][R32][512]
   int n_layers, R, R32, bm, Tc, Ls, parity, teams_pad, rpt;   // rpt: rows per team (<= 32)
+  int xshare;       // encoder attention per (sentence, segment) with the beams sharing the loads (1) or row by row (0)
   long long* stamps;   // diagnostics (SKHIP_STACK_STAMPS=1): 100 MHz clock at the phase boundaries of layer 3, team 0 member 0
   float scale, eps;
 };
@@ -66,6 +67,11 @@ constexpr int L_A = 32768;                // same layout: attention rows gathere
 constexpr int L_HS = 65536;               // [32][256] bf16 hidden slice, same swizzle
 constexpr int L_QKV = 81920;              // q | k | v [3][32][64] bf16, plain rows
 constexpr int L_BYTES = 94208;
+// encoder attention by (sentence, 32-position segment): a segment's un-normalised P.V sums [XSEG_MAX][ROWS][64] fp32 and
+// (maximum, sum) pairs [XSEG_MAX][ROWS][2] lie over the A and HS images, which nobody uses during that phase
+constexpr int XSEG = 32, XSEG_MAX = 5;    // source sentences of at most 160 positions take this path
+constexpr int L_XACC = L_A, L_XML = L_A + XSEG_MAX * ROWS * DH * 4;
+static_assert(L_XML + XSEG_MAX * ROWS * 2 * 4 <= L_QKV, "segment results must fit over the A and HS images");
 
 struct TeamCtx {
   int32_t* flag;
@@ -349,6 +355,105 @@ __device__ __forceinline__ void attend(const AttRows<NR>& rw, float scale, const
   }
 }
 
+// ---- encoder attention with the beams of a sentence sharing its keys / values.  The rows of a sentence (its beams)
+// attend to the SAME encoder keys and values, so the unit of work is (sentence, segment of 32 source positions): a wave
+// loads the segment once (four keys and four values per lane, all in flight together) and runs every row of the
+// sentence that belongs to the team against it, leaving per (row, segment) the maximum score, the sum of
+// exponentials against it and the un-normalised P.V sums in LDS; merge_xsegments() combines a row's segments.
+// (Row by row, attend() loads the sentence's keys / values once per beam: five times the loads and their address
+// arithmetic, and with 20 rows on 8 waves half of the waves make two passes.)
+// Lane = (position group rg = lane / 8, 16-byte chunk ch = lane % 8): positions j0 + rg + 8 i, i = 0 .. 3.
+__device__ __forceinline__ void attend_shared(const bf16_t* q_lds, int r_lo, int r_hi, int sent, int j0, int seg, int Ls,
+                                              float scale, const bf16_t* Kh, const bf16_t* Vh, const uint8_t* key_pad,
+                                              float* xacc, float* xml, int lane) {
+  const int ch = lane & 7, rg = lane >> 3;
+  const uint32_t ones = 0x3f803f80u;   // bf16 (1, 1)
+  uint4 kq[4], vq[4];
+  bool ok[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int pos = j0 + rg + 8 * i;
+    const int pc = min(pos, Ls - 1);   // clamped: loads stay inside the sentence
+    const int64_t jr = (int64_t)sent * Ls + pc;
+    ok[i] = pos < Ls && !key_pad[jr];
+    kq[i] = *(const uint4*)(Kh + jr * D + 8 * ch);
+    vq[i] = *(const uint4*)(Vh + jr * D + 8 * ch);
+  }
+#pragma unroll 1
+  for (int r = r_lo; r < r_hi; ++r) {
+    const uint4 qv = *(const uint4*)(q_lds + r * DH + 8 * ch);
+    float sc[4], mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float d = dot2(kq[i].x, qv.x, 0.f);
+      d = dot2(kq[i].y, qv.y, d);
+      d = dot2(kq[i].z, qv.z, d);
+      d = dot2(kq[i].w, qv.w, d);
+      d = group8_sum(d) * scale;
+      sc[i] = ok[i] ? d : -INFINITY;
+      mx = fmaxf(mx, sc[i]);
+    }
+    mx = fmaxf(mx, xor8(mx));
+    mx = fmaxf(mx, xor16(mx));
+    mx = fmaxf(mx, xor32(mx));
+    const bool any = mx != -INFINITY;
+    float acc[8], ls = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; i += 2) {
+      const float p0 = any ? __expf(sc[i] - mx) : 0.f, p1 = any ? __expf(sc[i + 1] - mx) : 0.f;
+      const uint32_t pp = pack_bf16x2(p0, p1);
+      ls = dot2(pp, ones, ls);
+      const uint32_t va[4] = {vq[i].x, vq[i].y, vq[i].z, vq[i].w};
+      const uint32_t vb[4] = {vq[i + 1].x, vq[i + 1].y, vq[i + 1].z, vq[i + 1].w};
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        acc[2 * d] = dot2(__builtin_amdgcn_perm(vb[d], va[d], 0x05040100u), pp, acc[2 * d]);
+        acc[2 * d + 1] = dot2(__builtin_amdgcn_perm(vb[d], va[d], 0x07060302u), pp, acc[2 * d + 1]);
+      }
+    }
+    ls += xor8(ls);
+    ls += xor16(ls);
+    ls += xor32(ls);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float v = acc[e];
+      v += xor8(v);
+      v += xor16(v);
+      v += xor32(v);
+      acc[e] = v;
+    }
+    if (rg == 0) {
+      float* o = xacc + (seg * ROWS + r) * DH + 8 * ch;
+      *(float4*)o = make_float4(acc[0], acc[1], acc[2], acc[3]);
+      *(float4*)(o + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+      if (ch == 0) *(float2*)(xml + 2 * (seg * ROWS + r)) = make_float2(mx, ls);
+    }
+  }
+}
+
+// a row's segments -> its attention output (bf16, head m's 64 columns of att): thread = (row tid / 16, 4 columns)
+__device__ __forceinline__ void merge_xsegments(const float* xacc, const float* xml, bf16_t* att, int nseg, int row0, int R,
+                                                int m, int tid) {
+  const int r = tid >> 4, c = 4 * (tid & 15), rg = row0 + r;
+  if (rg >= R) return;
+  float M = -INFINITY;
+  for (int sg = 0; sg < nseg; ++sg) M = fmaxf(M, xml[2 * (sg * ROWS + r)]);
+  float den = 0.f, num[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int sg = 0; sg < nseg; ++sg) {
+    const int it = sg * ROWS + r;
+    const float2 ml = *(const float2*)(xml + 2 * it);
+    const float w = ml.x == -INFINITY ? 0.f : __expf(ml.x - M);
+    const float4 a = *(const float4*)(xacc + it * DH + c);
+    den += ml.y * w;
+    num[0] += a.x * w; num[1] += a.y * w; num[2] += a.z * w; num[3] += a.w * w;
+  }
+  const float inv = 1.0f / den;   // a fully masked row: 0 / 0, as in the row-by-row form
+  const float o[4] = {num[0] * inv, num[1] * inv, num[2] * inv, num[3] * inv};
+  *(uint2*)(att + (int64_t)rg * D + DH * m + c) = pack4(o);
+}
+
 // gather the team's 32 attention rows (bf16 [.][512]) into the swizzled LDS image
 __device__ __forceinline__ void load_att(char* A, const bf16_t* att, int row0, int R, int tid) {
   uint4 v[4];
@@ -547,7 +652,23 @@ __global__ __launch_bounds__(NTHREADS) void decode_stack_kernel(StackArgs a) {
     }
     __syncthreads();
     STAMP();  // 6: after LN + cross-q
-    {
+    if (a.Ls <= XSEG * XSEG_MAX && a.xshare) {
+      // the team's (sentence, segment) pairs, dealt out to the waves round-robin; then the rows' segments are merged
+      IDS();
+      const int s_lo = row0 / a.bm, s_hi = (R - 1) / a.bm, nseg = (a.Ls + XSEG - 1) / XSEG;
+      const int total = (s_hi - s_lo + 1) * nseg;
+      float* xacc = (float*)(smem + L_XACC);
+      float* xml = (float*)(smem + L_XML);
+#pragma unroll 1
+      for (int it = wave; it < total; it += NTHREADS / 64) {
+        const int sent = s_lo + it / nseg, seg = it - (it / nseg) * nseg;
+        const int r_lo = max(sent * a.bm, row0) - row0, r_hi = min((sent + 1) * a.bm, R) - row0;
+        attend_shared(QKV, r_lo, r_hi, sent, XSEG * seg, seg, a.Ls, a.scale, P.crossK + DH * m, P.crossV + DH * m,
+                      a.src_key_pad, xacc, xml, lane);
+      }
+      __syncthreads();
+      merge_xsegments(xacc, xml, a.att, nseg, row0, R, m, tid);
+    } else {
     IDS();
 #pragma unroll 1
     for (int i = 0; i < 4; i += 2) {
@@ -749,6 +870,7 @@ extern "C" int skhip_decode_stack(const int64_t* layers, int n_layers, const int
   a.n_layers = n_layers; a.R = R; a.R32 = R32; a.bm = bm; a.Tc = Tc; a.Ls = Ls; a.parity = parity; a.rpt = rpt;
   a.teams_pad = (n_teams + 7) / 8 * 8;   // members of a team sit at the same block index modulo 8
   a.scale = scale; a.eps = eps;
+  { const char* e = getenv("SKHIP_STACK_XSHARE"); a.xshare = !(e && e[0] == '0'); }
   a.stamps = getenv("SKHIP_STACK_STAMPS") ? (long long*)(ws + 512) : nullptr;
   static bool attr_set = false;
   if (!attr_set) {

@@ -74,3 +74,25 @@ def test_stack_search_agrees_with_op_by_op_search():
     same = sum(a == b for a, b in zip(h0, h1))
     assert same >= 36, same
     assert h1 == h2 and [x.tolist() for x in s1] == [x.tolist() for x in s2]
+
+
+def test_stack_encoder_attention_forms_agree(monkeypatch):
+    """The encoder attention of the one-launch stack has two forms — per (sentence, 32-position segment) with the
+    beams of a sentence sharing the loaded keys / values (source sentences of at most 160 positions), and row by row
+    (longer ones; SKHIP_STACK_XSHARE=0 forces it): same hypotheses and scores to bf16 rounding on a batch whose
+    sentences straddle team boundaries (7 sentences x 5 beams = 35 rows in teams of 18)."""
+    from specialk_amd.decode import BeamDecoder
+    m = build(2)
+    src, pos = batch(7, 3, 17, 1000, 4)
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("SKHIP_STACK_XSHARE", mode)
+        dec = BeamDecoder(m, 5, 12, use_graph=False, use_stack=True)
+        dec.trace = []
+        hyps, scores = dec.run(src, pos, 2)
+        assert dec.used_stack
+        res[mode] = (hyps, [x.tolist() for x in scores], [t[0].float() for t in dec.trace])
+    same = sum(a == b for a, b in zip(res["1"][0], res["0"][0]))
+    assert same >= 6, same   # (random weights leave near-ties that a different summation order may break differently)
+    a, b = res["1"][2][0], res["0"][2][0]   # the first step's decoder output: identical histories by construction
+    assert float((a - b).abs().max() / b.abs().max()) <= 2e-2
