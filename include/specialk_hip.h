@@ -355,6 +355,9 @@ int skhip_beam_topk_stats(const float* logits, const float* stats, const float* 
  *   {Wqkv bf16 [1536][512] (rows q | k | v), bqkv f32 [1536], Wo bf16 [512][512], bo, ln1 gamma, ln1 beta,
  *    Wq_enc bf16 [512][512], bq_enc, Wo_enc bf16 [512][512], bo_enc, ln2 gamma, ln2 beta,
  *    W1 bf16 [2048][512], b1, W2 bf16 [512][2048], b2, ln3 gamma, ln3 beta,
+ *    — the six weight MATRICES not in their [rows][K] layout but fragment-major, [rows / 16][K / 32][64][8]: element
+ *    (row 16 a + r, column 32 b + 8 g + j) at (((a * K / 32 + b) * 64 + r + 16 g) * 8 + j), which is the order the
+ *    kernel's matrix instructions consume them in (whole 128-byte lines per load instruction) —
  *    Kcache, Vcache bf16 [R][Tc][512], encK, encV bf16 [n_sent][Ls][512]}   (all 16-byte aligned).
  * tok, pos int64 [R]; cur_len int32 [R] (history length of row r including the new position); row_pad uint8 [R];
  * pad_hist uint8 [R][Tc]; hist int32 [R][Tc] (history-row table as for skhip_decode_attn); src_key_pad uint8

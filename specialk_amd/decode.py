@@ -150,13 +150,27 @@ class BeamDecoder:
                  and R <= 32 * (torch.cuda.get_device_properties(dev).multi_processor_count // 8))
         if stack:
             f32 = lambda p: p.detach().float().contiguous()
+
+            def frag_major(mats):
+                """The kernel reads its weight matrices fragment-major, [rows / 16][K / 32][64 lanes][8]: matrices of
+                one shape are permuted together (one copy kernel per shape, every call: the optimiser updates weights
+                in place without touching version counters, so nothing here may be cached)."""
+                W = torch.stack(mats)
+                n_, N_, K_ = W.shape
+                return W.view(n_, N_ // 16, 16, K_ // 32, 4, 8).permute(0, 1, 3, 4, 2, 5).contiguous()
+
+            fm_qkv = frag_major(qkv_w)
+            fm_sq = frag_major([self._w(p, dt) for l in layers for p in (l.slf_attn.fc.weight, l.enc_attn.w_qs.weight,
+                                                                          l.enc_attn.fc.weight)])
+            fm_w1 = frag_major([self._w(l.pos_ffn.w_1.weight, dt) for l in layers])
+            fm_w2 = frag_major([self._w(l.pos_ffn.w_2.weight, dt) for l in layers])
             rows, keep = [], []
             for li, l in enumerate(layers):
                 s_, c_, f_ = l.slf_attn, l.enc_attn, l.pos_ffn
-                row = [qkv_w[li], qkv_b[li], self._w(s_.fc.weight, dt), f32(s_.fc.bias), f32(s_.layer_norm.weight),
-                       f32(s_.layer_norm.bias), self._w(c_.w_qs.weight, dt), f32(c_.w_qs.bias), self._w(c_.fc.weight, dt),
-                       f32(c_.fc.bias), f32(c_.layer_norm.weight), f32(c_.layer_norm.bias), self._w(f_.w_1.weight, dt),
-                       f32(f_.w_1.bias), self._w(f_.w_2.weight, dt), f32(f_.w_2.bias), f32(f_.layer_norm.weight),
+                row = [fm_qkv[li], qkv_b[li], fm_sq[3 * li], f32(s_.fc.bias), f32(s_.layer_norm.weight),
+                       f32(s_.layer_norm.bias), fm_sq[3 * li + 1], f32(c_.w_qs.bias), fm_sq[3 * li + 2],
+                       f32(c_.fc.bias), f32(c_.layer_norm.weight), f32(c_.layer_norm.bias), fm_w1[li],
+                       f32(f_.w_1.bias), fm_w2[li], f32(f_.w_2.bias), f32(f_.layer_norm.weight),
                        f32(f_.layer_norm.bias), Kc[li], Vc[li], crossK[li], crossV[li]]
                 rows.append(row)
                 keep.append(row)
