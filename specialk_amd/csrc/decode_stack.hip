@@ -158,21 +158,29 @@ __device__ __forceinline__ uint2 pack4(const float (&v)[4]) {
   return o;
 }
 
-// ---- LayerNorm of 32 rows of the team's fp32 exchange buffer into the LDS image X (wave w: rows 4 w .. 4 w + 3; a
-// lane owns 8 consecutive columns; same arithmetic as add_ln_fwd_kernel of layernorm.hip).
+// ---- LayerNorm of the team's rows of the fp32 exchange buffer into the LDS image X (wave w: rows w, w + 8, w + 16,
+// w + 24 — with 20 rows per team every wave then has two or three of them instead of five waves four each; a lane
+// owns 8 consecutive columns; same arithmetic as add_ln_fwd_kernel of layernorm.hip).  Rows beyond the team's last
+// one are left as they are in X: the products run over all 32 image rows and their results are never stored.
 __device__ __forceinline__ void ln_rows(char* X, const float* z, int row0, int R, const float* gamma, const float* beta,
                                         const uint8_t* row_pad, float eps, int wave, int lane) {
   float4 zz[4][2];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {   // all rows' loads in flight together
-    const float4* zp = (const float4*)(z + (int64_t)min(row0 + 4 * wave + i, R - 1) * D + 8 * lane);
+    const float4* zp = (const float4*)(z + (int64_t)min(row0 + wave + 8 * i, R - 1) * D + 8 * lane);
     zz[i][0] = zp[0];
     zz[i][1] = zp[1];
   }
+  const float4* gp = (const float4*)(gamma + 8 * lane);
+  const float4* bp = (const float4*)(beta + 8 * lane);
+  const float4 g0 = gp[0], g1 = gp[1], b0 = bp[0], b1 = bp[1];
+  const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+  const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int r = 4 * wave + i;
-    const int rg = min(row0 + r, R - 1);
+    const int r = wave + 8 * i;
+    if (row0 + r >= R) break;   // wave-uniform
+    const int rg = row0 + r;
     const float4 z0 = zz[i][0], z1 = zz[i][1];
     const float v[8] = {z0.x, z0.y, z0.z, z0.w, z1.x, z1.y, z1.z, z1.w};
     float sum = 0.f;
@@ -184,11 +192,6 @@ __device__ __forceinline__ void ln_rows(char* X, const float* z, int row0, int R
     for (int j = 0; j < 8; ++j) { const float c = v[j] - mean; sq += c * c; }
     const float rstd = 1.0f / sqrtf(wave_sum(sq) / (float)D + eps);
     const bool pad = row_pad[rg] != 0;
-    const float4* gp = (const float4*)(gamma + 8 * lane);
-    const float4* bp = (const float4*)(beta + 8 * lane);
-    const float4 g0 = gp[0], g1 = gp[1], b0 = bp[0], b1 = bp[1];
-    const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
-    const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
     Vec16<bf16_t> o;
 #pragma unroll
     for (int j = 0; j < 8; ++j) o.set(j, pad ? 0.f : (v[j] - mean) * rstd * gg[j] + bb[j]);
