@@ -9,10 +9,10 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
-def build(n_layers, vocab=1000):
+def build(n_layers, vocab=1000, len_max=40):
     from specialk_amd.lib.transformer.Models import Transformer
     torch.manual_seed(5)
-    m = Transformer(vocab, vocab, 40, d_word_vec=512, d_model=512, d_inner=2048, n_layers=n_layers, n_head=8, d_k=64,
+    m = Transformer(vocab, vocab, len_max, d_word_vec=512, d_model=512, d_inner=2048, n_layers=n_layers, n_head=8, d_k=64,
                     d_v=64, tgt_emb_prj_weight_sharing=False, emb_src_tgt_weight_sharing=False)
     for p in m.parameters():
         if p.dim() > 1:
@@ -96,3 +96,27 @@ def test_stack_encoder_attention_forms_agree(monkeypatch):
     assert same >= 6, same   # (random weights leave near-ties that a different summation order may break differently)
     a, b = res["1"][2][0], res["0"][2][0]   # the first step's decoder output: identical histories by construction
     assert float((a - b).abs().max() / b.abs().max()) <= 2e-2
+
+
+def test_stack_long_histories_match_op_by_op():
+    """Histories of up to 150 positions (three 64-position sweeps of the self-attention, the length of the benchmark's
+    decode leg) and source sentences of up to 70 positions (three segments of the encoder attention): every step's
+    decoder output of the one-launch stack within 2e-2 of the op-by-op path's, the search's choices forced to be the
+    same."""
+    from specialk_amd.decode import BeamDecoder
+    m = build(1, len_max=160)
+    src, pos = batch(6, 30, 70, 1000, 9)
+    ref = BeamDecoder(m, 5, 150, use_graph=False, use_stack=False)
+    ref.trace = []
+    ref.run(src, pos, 1)
+    got = BeamDecoder(m, 5, 150, use_graph=False, use_stack=True)
+    got.trace, got.forced = [], [t[1:] for t in ref.trace]
+    got.run(src, pos, 1)
+    assert got.used_stack and len(got.trace) == len(ref.trace) >= 100
+    worst = 0.0
+    for step, (a, b) in enumerate(zip(got.trace, ref.trace)):
+        xa, xb = a[0].float(), b[0].float()
+        err = float((xa - xb).abs().max() / xb.abs().max())
+        worst = max(worst, err)
+        assert err <= 2e-2, (step, err)
+    print(f"worst relative difference over {len(ref.trace)} steps: {worst:.4f}")
