@@ -56,6 +56,8 @@ struct StackArgs {
   float* zbuf;      // [R32][512]
   float* pbuf;      // [8][R32][512]
   int n_layers, R, R32, bm, Tc, Ls, parity, teams_pad, rpt;   // rpt: rows per team (<= 32)
+  int fuse_red;     // the partial feed-forward products summed by every member (1) or by columns with one more team barrier (0)
+  int TcP;          // row length of the history table in LDS (Tc rounded up to 32), 0: self-attention by attend()
   int xshare;       // encoder attention per (sentence, segment) with the beams sharing the loads (1) or row by row (0)
   long long* stamps;   // diagnostics (SKHIP_STACK_STAMPS=1): 100 MHz clock at the phase boundaries of layer 3, team 0 member 0
   float scale, eps;
@@ -67,6 +69,8 @@ constexpr int L_A = 32768;                // same layout: attention rows gathere
 constexpr int L_HS = 65536;               // [32][256] bf16 hidden slice, same swizzle
 constexpr int L_QKV = 81920;              // q | k | v [3][32][64] bf16, plain rows
 constexpr int L_BYTES = 94208;
+constexpr int L_JT = L_BYTES;             // [32][TcP] history table of self_attend_pipe (when the launch carries it)
+constexpr int L_MAX = 160 * 1024;
 // encoder attention by (sentence, 32-position segment): a segment's un-normalised P.V sums [XSEG_MAX][ROWS][64] fp32 and
 // (maximum, sum) pairs [XSEG_MAX][ROWS][2] lie over the A and HS images, which nobody uses during that phase
 constexpr int XSEG = 32, XSEG_MAX = 5;    // source sentences of at most 160 positions take this path
@@ -196,6 +200,70 @@ __device__ __forceinline__ void ln_rows(char* X, const float* z, int row0, int R
 #pragma unroll
     for (int j = 0; j < 8; ++j) o.set(j, pad ? 0.f : (v[j] - mean) * rstd * gg[j] + bb[j]);
     *(uint4*)(X + r * 1024 + ((lane ^ (r & 15)) << 4)) = o.v;
+  }
+}
+
+// ---- the same LayerNorm fed from the team's 8 partial second feed-forward products: every member sums ALL columns of
+// its team's rows itself (partials in member order, + bias, rounded to bf16, + the residual held in X — the arithmetic
+// of a reduce into the exchange buffer followed by ln_rows) instead of summing its 64 columns, publishing them and
+// meeting the team once more.  8 x the reads of the partials (they sit in the L2) against one team barrier less:
+// 0.663 against 0.677 ms per step.  (The attention blocks' output projections do not gain from the same trade — each
+// member multiplying its own head's outputs by a 64-column slice of the matrix, K = 64, and every member summing the
+// eight partial products: one barrier instead of two per block, but 0.674 - 0.684 ms per step.)
+__device__ __forceinline__ void ln_rows_partials(char* X, const float* pbuf, int R32, int row0, int R, const float* b2,
+                                                 const float* gamma, const float* beta, const uint8_t* row_pad, float eps,
+                                                 int wave, int lane) {
+  const float4* gp = (const float4*)(gamma + 8 * lane);
+  const float4* bp = (const float4*)(beta + 8 * lane);
+  const float4* cp = (const float4*)(b2 + 8 * lane);
+  const float4 g0 = gp[0], g1 = gp[1], b0 = bp[0], b1 = bp[1], c0 = cp[0], c1 = cp[1];
+  const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+  const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+  const float cc[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+#pragma unroll
+  for (int ip = 0; ip < 4; ip += 2) {   // two rows' sixteen partial slices in flight together
+    float4 pp[2][TEAM][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int mm = 0; mm < TEAM; ++mm) {
+        const float4* q = (const float4*)(pbuf + ((int64_t)mm * R32 + min(row0 + wave + 8 * (ip + i), R - 1)) * D + 8 * lane);
+        pp[i][mm][0] = q[0];
+        pp[i][mm][1] = q[1];
+      }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int r = wave + 8 * (ip + i);
+      if (row0 + r >= R) break;   // wave-uniform
+      const int rg = row0 + r;
+      float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int mm = 0; mm < TEAM; ++mm) {
+        s[0] += pp[i][mm][0].x; s[1] += pp[i][mm][0].y; s[2] += pp[i][mm][0].z; s[3] += pp[i][mm][0].w;
+        s[4] += pp[i][mm][1].x; s[5] += pp[i][mm][1].y; s[6] += pp[i][mm][1].z; s[7] += pp[i][mm][1].w;
+      }
+      const uint4 raw = *(const uint4*)(X + r * 1024 + ((lane ^ (r & 15)) << 4));
+      const uint32_t rw[4] = {raw.x, raw.y, raw.z, raw.w};
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float res = bf16_to_f32((bf16_t)((j & 1) ? (rw[j >> 1] >> 16) : (rw[j >> 1] & 0xffff)));
+        v[j] = round_bf16(s[j] + cc[j]) + res;
+      }
+      float sum = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) sum += v[j];
+      const float mean = wave_sum(sum) / (float)D;
+      float sq = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const float c = v[j] - mean; sq += c * c; }
+      const float rstd = 1.0f / sqrtf(wave_sum(sq) / (float)D + eps);
+      const bool pad = row_pad[rg] != 0;
+      Vec16<bf16_t> o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o.set(j, pad ? 0.f : (v[j] - mean) * rstd * gg[j] + bb[j]);
+      *(uint4*)(X + r * 1024 + ((lane ^ (r & 15)) << 4)) = o.v;
+    }
   }
 }
 
@@ -361,6 +429,196 @@ __device__ __forceinline__ void attend(const AttRows<NR>& rw, float scale, const
       for (int e = 0; e < 8; ++e) ov.set(e, accv[x][e] * inv);
       *(uint4*)(rw.out[x] + ch * 8) = ov.v;
     }
+  }
+}
+
+// ---- self-attention of a wave's rows as a software pipeline.  attend() above runs a sweep as: history-row table ->
+// keys / values -> arithmetic, two memory round trips and the arithmetic one after the other, twice per row pair at
+// history lengths 65 .. 128, and for a missing row of a pair it still issues that row's loads.  Here
+//   - the history-row table of the team's rows is staged in LDS once per launch (all layers index the caches alike):
+//     entry (r, p) = cache row of position p of row r's history * Tc + p, bit 31 = that position is padding;
+//   - the newest position — whose key / value exist in LDS only — is appended to the caches up front and folded into
+//     the softmax at the end, so that the sweeps see cached positions only and issue their loads unconditionally;
+//   - a stage is 32 positions of a row pair (sixteen 16-byte loads per lane); the loads of stage s + 1 are issued
+//     before the arithmetic of stage s, across the boundary between the wave's two row pairs as well.
+// Results are left in the rows' query slots in LDS (a row's query is read by its own wave only) and copied out at
+// the end.  Lane = (position group lane / 8, 16-byte chunk lane % 8), positions 32 w + group + 8 i, i = 0 .. 3.
+struct KVStage {
+  uint4 k[2][4], v[2][4];
+  uint32_t ok;   // bit 4 x + i: position i of row x is inside the history and not padding
+};
+
+struct SelfRows {
+  int n[4];    // positions of the wave's rows wave + 8 i, newest included (0: no such row)
+  int ns[2];   // stages of the two row pairs
+};
+
+__device__ __forceinline__ void self_issue(KVStage& st, const SelfRows& sr, const int32_t* JT, int TcP, const bf16_t* Kh,
+                                           const bf16_t* Vh, int wave, int s, int lane) {
+  const int ch = lane & 7, rg = lane >> 3;
+  const int total = sr.ns[0] + sr.ns[1];
+  const int sc = min(s, total - 1);   // past the end: the last stage once more
+  const int p = sc >= sr.ns[0] ? 1 : 0, w = sc - (p ? sr.ns[0] : 0);
+  uint32_t ok = 0;
+#pragma unroll
+  for (int x = 0; x < 2; ++x) {
+    const int nh = max((p ? sr.n[2 + x] : sr.n[x]) - 1, 0);   // cached positions
+    const int32_t* jt = JT + (wave + 8 * (2 * p + x)) * TcP;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int pos = 32 * w + rg + 8 * i;
+      const int32_t e = jt[min(pos, max(nh - 1, 0))];   // clamped: loads stay inside the row's history
+      const int64_t jr = e & 0x7fffffff;
+      st.k[x][i] = *(const uint4*)(Kh + jr * D + 8 * ch);
+      st.v[x][i] = *(const uint4*)(Vh + jr * D + 8 * ch);
+      if (pos < nh && e >= 0) ok |= 1u << (4 * x + i);
+    }
+  }
+  st.ok = ok;
+}
+
+struct SelfState {
+  float m[2], l[2], acc[2][8];
+};
+
+__device__ __forceinline__ void self_compute(const KVStage& st, SelfState& S, const SelfRows& sr, bf16_t* QKV, int wave,
+                                             int s, float scale, int lane) {
+  const int ch = lane & 7, rg = lane >> 3;
+  const int p = s >= sr.ns[0] ? 1 : 0, w = s - (p ? sr.ns[0] : 0);
+  const bool last = w == (p ? sr.ns[1] : sr.ns[0]) - 1;
+  const uint32_t ones = 0x3f803f80u;   // bf16 (1, 1)
+#pragma unroll
+  for (int x = 0; x < 2; ++x) {
+    const int r = wave + 8 * (2 * p + x);
+    const int n = p ? sr.n[2 + x] : sr.n[x];
+    const uint4 qv = *(const uint4*)(QKV + r * DH + 8 * ch);
+    float sc[4], mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float d = dot2(st.k[x][i].x, qv.x, 0.f);
+      d = dot2(st.k[x][i].y, qv.y, d);
+      d = dot2(st.k[x][i].z, qv.z, d);
+      d = dot2(st.k[x][i].w, qv.w, d);
+      d = group8_sum(d) * scale;
+      sc[i] = (st.ok >> (4 * x + i)) & 1 ? d : -INFINITY;
+      mx = fmaxf(mx, sc[i]);
+    }
+    mx = fmaxf(mx, xor8(mx));
+    mx = fmaxf(mx, xor16(mx));
+    mx = fmaxf(mx, xor32(mx));
+    const float mn = fmaxf(S.m[x], mx);
+    const bool any = mn != -INFINITY;
+    const float alpha = any ? __expf(S.m[x] - mn) : 1.f;
+    S.m[x] = mn;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) S.acc[x][e] *= alpha;
+    float ls = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; i += 2) {
+      const float p0 = any ? __expf(sc[i] - mn) : 0.f, p1 = any ? __expf(sc[i + 1] - mn) : 0.f;
+      const uint32_t pp = pack_bf16x2(p0, p1);
+      ls = dot2(pp, ones, ls);
+      const uint32_t va[4] = {st.v[x][i].x, st.v[x][i].y, st.v[x][i].z, st.v[x][i].w};
+      const uint32_t vb[4] = {st.v[x][i + 1].x, st.v[x][i + 1].y, st.v[x][i + 1].z, st.v[x][i + 1].w};
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        S.acc[x][2 * d] = dot2(__builtin_amdgcn_perm(vb[d], va[d], 0x05040100u), pp, S.acc[x][2 * d]);
+        S.acc[x][2 * d + 1] = dot2(__builtin_amdgcn_perm(vb[d], va[d], 0x07060302u), pp, S.acc[x][2 * d + 1]);
+      }
+    }
+    S.l[x] = S.l[x] * alpha + ls;   // this group's share
+    if (last) {   // wave-uniform: the row's cached positions are done — add the groups up, fold the newest position in
+      if (n > 0) {
+        float lt = S.l[x];
+        lt += xor8(lt);
+        lt += xor16(lt);
+        lt += xor32(lt);
+        const uint4 kn = *(const uint4*)(QKV + (ROWS + r) * DH + 8 * ch);
+        const uint4 vn = *(const uint4*)(QKV + (2 * ROWS + r) * DH + 8 * ch);
+        float d = dot2(kn.x, qv.x, 0.f);
+        d = dot2(kn.y, qv.y, d);
+        d = dot2(kn.z, qv.z, d);
+        d = dot2(kn.w, qv.w, d);
+        d = group8_sum(d) * scale;
+        const float mf = fmaxf(S.m[x], d);
+        const float af = __expf(S.m[x] - mf);   // no cached position counted: exp(-inf) = 0
+        const float pn = round_bf16(__expf(d - mf));
+        const float inv = 1.0f / (lt * af + pn);
+        const uint32_t vw[4] = {vn.x, vn.y, vn.z, vn.w};
+        Vec16<bf16_t> ov;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float v = S.acc[x][e];
+          v += xor8(v);
+          v += xor16(v);
+          v += xor32(v);
+          const float vne = bf16_to_f32((bf16_t)((e & 1) ? (vw[e >> 1] >> 16) : (vw[e >> 1] & 0xffff)));
+          ov.set(e, (v * af + pn * vne) * inv);
+        }
+        if (rg == 0) *(uint4*)(QKV + r * DH + 8 * ch) = ov.v;
+      }
+      S.m[x] = -INFINITY;
+      S.l[x] = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) S.acc[x][e] = 0.f;
+    }
+  }
+}
+
+// att: the team's first row of the attention buffer, head m's columns; Kc / Vc: the layer's caches at head m's columns
+__device__ __forceinline__ void self_attend_pipe(const int32_t* JT, int TcP, bf16_t* QKV, const int32_t* cur_len, int Tc,
+                                                 bf16_t* Kc, bf16_t* Vc, bf16_t* att, int row0, int R, float scale,
+                                                 int wave, int lane) {
+  const int ch = lane & 7, rg = lane >> 3;
+  SelfRows sr;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int rgl = row0 + wave + 8 * i;
+    sr.n[i] = rgl < R ? min(cur_len[min(rgl, R - 1)], Tc) : 0;
+  }
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const int nmax = max(sr.n[2 * p], sr.n[2 * p + 1]);
+    sr.ns[p] = nmax > 0 ? max((nmax - 1 + 31) >> 5, 1) : 0;   // (a row with the newest position only still takes a stage)
+  }
+  const int total = sr.ns[0] + sr.ns[1];
+  if (total == 0) return;
+  // the newest position joins the caches: groups 0 / 1 store the key / value chunks
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (sr.n[i] == 0) continue;
+    const int r = wave + 8 * i;
+    const int64_t jr = JT[r * TcP + sr.n[i] - 1] & 0x7fffffff;
+    if (rg == 0) *(uint4*)(Kc + jr * D + 8 * ch) = *(const uint4*)(QKV + (ROWS + r) * DH + 8 * ch);
+    if (rg == 1) *(uint4*)(Vc + jr * D + 8 * ch) = *(const uint4*)(QKV + (2 * ROWS + r) * DH + 8 * ch);
+  }
+  SelfState S;
+#pragma unroll
+  for (int x = 0; x < 2; ++x) {
+    S.m[x] = -INFINITY;
+    S.l[x] = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) S.acc[x][e] = 0.f;
+  }
+  KVStage A, B;
+  self_issue(A, sr, JT, TcP, Kc, Vc, wave, 0, lane);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll 1
+  for (int s = 0; s < total; s += 2) {
+    self_issue(B, sr, JT, TcP, Kc, Vc, wave, s + 1, lane);
+    __builtin_amdgcn_sched_barrier(0);
+    self_compute(A, S, sr, QKV, wave, s, scale, lane);
+    __builtin_amdgcn_sched_barrier(0);
+    if (s + 1 >= total) break;
+    self_issue(A, sr, JT, TcP, Kc, Vc, wave, s + 2, lane);
+    __builtin_amdgcn_sched_barrier(0);
+    self_compute(B, S, sr, QKV, wave, s + 1, scale, lane);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  // the wave's rows -> the attention buffer (lanes 0 .. 31: row lane / 8, chunk lane % 8)
+  if (lane < 32 && sr.n[0] > 0) {   // (n[i] > 0 only if n[0] > 0: rows are dealt out in order)
+    const int i = lane >> 3, r = wave + 8 * i;
+    if (row0 + r < R) *(uint4*)(att + (int64_t)r * D + 8 * ch) = *(const uint4*)(QKV + r * DH + 8 * ch);
   }
 }
 
@@ -551,6 +809,39 @@ __global__ __launch_bounds__(NTHREADS) void decode_stack_kernel(StackArgs a) {
     o.set(4, w1.x + p1.x); o.set(5, w1.y + p1.y); o.set(6, w1.z + p1.z); o.set(7, w1.w + p1.w);
     *(uint4*)(X + r * 1024 + ((lane ^ (r & 15)) << 4)) = o.v;
   }
+  // history table: per thread 8 entries at a time, their two dependent loads in flight together
+  if (a.TcP) {
+    int32_t* JT = (int32_t*)(smem + L_JT);
+    const int n_ent = ROWS * a.TcP;
+#pragma unroll 1
+    for (int base = 0; base < n_ent; base += 8 * NTHREADS) {
+      int32_t h[8], pc[8];
+      uint8_t pd[8];
+      int64_t hrow[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int idx = min(base + tid + NTHREADS * u, n_ent - 1);
+        const int r = idx / a.TcP, pp = idx - r * a.TcP;
+        const int rgl = min(row0 + r, R - 1);
+        pc[u] = min(pp, a.Tc - 1);
+        hrow[u] = (int64_t)rgl * a.Tc;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) h[u] = a.hist[hrow[u] + pc[u]];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        // (entries past a row's length are never used: the table there holds whatever the history table does,
+        // clamped into the cache so that even a stray use would stay inside it)
+        h[u] = min(max(h[u], 0), a.R - 1) * a.Tc + pc[u];
+        pd[u] = a.pad_hist[h[u]];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int idx = base + tid + NTHREADS * u;
+        if (idx < n_ent) JT[idx] = h[u] | (pd[u] ? (int32_t)0x80000000 : 0);
+      }
+    }
+  }
   }
   __syncthreads();
 
@@ -594,6 +885,11 @@ __global__ __launch_bounds__(NTHREADS) void decode_stack_kernel(StackArgs a) {
     STAMP();  // 1: after A
     // ---- B: self-attention of head m (wave w: the team's rows w, w + 8, w + 16, w + 24, two at a time), appending
     // the new key / value
+    if (a.TcP) {
+      IDS();
+      self_attend_pipe((const int32_t*)(smem + L_JT), a.TcP, QKV, a.cur_len, a.Tc, P.Kc + DH * m, P.Vc + DH * m,
+                       a.att + (int64_t)row0 * D + DH * m, row0, R, a.scale, wave, lane);
+    } else
     {
     IDS();
 #pragma unroll 1
@@ -779,6 +1075,13 @@ __global__ __launch_bounds__(NTHREADS) void decode_stack_kernel(StackArgs a) {
     STAMP();  // 12: after G
     team_sync(ctx);
     STAMP();  // 13: after sync 5
+    if (a.fuse_red) {
+      // ---- the partial products summed by every member for all columns, + bias, + residual, LayerNorm -> X
+      IDS();
+      ln_rows_partials(X, a.pbuf, a.R32, row0, R, P.b2, P.g3, P.be3, a.row_pad, a.eps, wave, lane);
+      STAMP();  // 14
+      STAMP();  // 15
+    } else {
     // ---- reduce the 8 partial products for columns 64 m .. (fixed order), + bias, + residual -> z
     {
       IDS();
@@ -808,6 +1111,7 @@ __global__ __launch_bounds__(NTHREADS) void decode_stack_kernel(StackArgs a) {
     {
     IDS();
     ln_rows(X, a.zbuf, row0, R, P.g3, P.be3, a.row_pad, a.eps, wave, lane);
+    }
     }
     __syncthreads();
     STAMP();  // 16: after LN
@@ -880,14 +1184,19 @@ extern "C" int skhip_decode_stack(const int64_t* layers, int n_layers, const int
   a.teams_pad = (n_teams + 7) / 8 * 8;   // members of a team sit at the same block index modulo 8
   a.scale = scale; a.eps = eps;
   { const char* e = getenv("SKHIP_STACK_XSHARE"); a.xshare = !(e && e[0] == '0'); }
+  { const char* e = getenv("SKHIP_STACK_FUSERED"); a.fuse_red = !(e && e[0] == '0'); }
   a.stamps = getenv("SKHIP_STACK_STAMPS") ? (long long*)(ws + 512) : nullptr;
+  // the history table rides in LDS when it fits beside the images (history rows of up to 512 positions)
+  a.TcP = (Tc + 31) / 32 * 32;
+  { const char* e = getenv("SKHIP_STACK_PIPE"); if ((e && e[0] == '0') || L_JT + ROWS * a.TcP * 4 > L_MAX) a.TcP = 0; }
+  const int lds_bytes = a.TcP ? L_JT + ROWS * a.TcP * 4 : L_BYTES;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)decode_stack_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, L_BYTES);
+    hipError_t e = hipFuncSetAttribute((const void*)decode_stack_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, L_MAX);
     if (e != hipSuccess) { sk_set_error("skhip_decode_stack: LDS attribute: %s", hipGetErrorString(e)); return SK_ERR_LAUNCH; }
     attr_set = true;
   }
-  hipLaunchKernelGGL(decode_stack_kernel, dim3((unsigned)(a.teams_pad * TEAM)), dim3(NTHREADS), L_BYTES, stream, a);
+  hipLaunchKernelGGL(decode_stack_kernel, dim3((unsigned)(a.teams_pad * TEAM)), dim3(NTHREADS), lds_bytes, stream, a);
   SK_CHECK_LAUNCH("skhip_decode_stack");
   return SK_OK;
 }
