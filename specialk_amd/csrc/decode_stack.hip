@@ -59,6 +59,7 @@ struct StackArgs {
   int fuse_red;     // the partial feed-forward products summed by every member (1) or by columns with one more team barrier (0)
   int TcP;          // row length of the history table in LDS (Tc rounded up to 32), 0: self-attention by attend()
   int xshare;       // encoder attention per (sentence, segment) with the beams sharing the loads (1) or row by row (0)
+  int stamp_block, stamp_tid;   // who writes the stamps
   long long* stamps;   // diagnostics (SKHIP_STACK_STAMPS=1): 100 MHz clock at the phase boundaries of layer 3, team 0 member 0
   float scale, eps;
 };
@@ -84,14 +85,21 @@ struct TeamCtx {
   bool dead;
 };
 
-__device__ __forceinline__ void team_sync(TeamCtx& c) {
+// prefetch(): loads of the NEXT phase's weights, issued by every wave between announcing its arrival and waiting for
+// the others, so that their trip to memory runs beside the barrier's own round trips.  (Issued before the barrier,
+// they sit in front of the wait for the stores, and the team meets two microseconds later.)
+template <class F>
+__device__ __forceinline__ void team_sync(TeamCtx& c, F&& prefetch) {
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // this wave's stores have reached the L2
   __syncthreads();
   c.count += 1;
-  if (threadIdx.x == 0 && !c.dead) {
-    const int target = TEAM * c.count;
-    // the value the increment returns already tells the last arriver that everybody is here: no poll for it
-    int seen = __hip_atomic_fetch_add(c.flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+  const int target = TEAM * c.count;
+  const bool leader = threadIdx.x == 0 && !c.dead;
+  int seen = target;
+  // the value the increment returns already tells the last arriver that everybody is here: no poll for it
+  if (leader) seen = __hip_atomic_fetch_add(c.flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+  prefetch();
+  if (leader) {
     int spins = 0;
     while (seen < target) {
       __builtin_amdgcn_s_sleep(1);
@@ -106,6 +114,7 @@ __device__ __forceinline__ void team_sync(TeamCtx& c) {
   __syncthreads();
   asm volatile("buffer_inv sc0" ::: "memory");   // forget this CU's L1 lines: the team's slices are read from the L2
 }
+__device__ __forceinline__ void team_sync(TeamCtx& c) { team_sync(c, [] {}); }
 
 // ---- MFMA pieces.  v_mfma_f32_16x16x32_bf16(w, a): lane (l15 = lane & 15, g = lane >> 4) supplies k = 8 g .. 8 g + 7
 // of weight row l15 and of activation row l15, and receives out[activation row l15][weight rows 4 g .. 4 g + 3].
@@ -630,8 +639,33 @@ __device__ __forceinline__ void self_attend_pipe(const int32_t* JT, int TcP, bf1
 // (Row by row, attend() loads the sentence's keys / values once per beam: five times the loads and their address
 // arithmetic, and with 20 rows on 8 waves half of the waves make two passes.)
 // Lane = (position group rg = lane / 8, 16-byte chunk ch = lane % 8): positions j0 + rg + 8 i, i = 0 .. 3.
-__device__ __forceinline__ void attend_shared(const bf16_t* q_lds, int r_lo, int r_hi, int sent, int j0, int seg, int Ls,
-                                              float scale, const bf16_t* Kh, const bf16_t* Vh, const uint8_t* key_pad,
+// The segment's keys / values do not depend on the queries: a wave requests those of its first (sentence, segment) pair
+// before the LayerNorm and the query projection of the phase, which then hide the trip to memory.
+struct XSeg {
+  uint4 kq[4], vq[4];
+  uint32_t ok;   // bit i: position i is inside the sentence and not padding
+};
+
+__device__ __forceinline__ void xseg_load(XSeg& xs, int sent, int j0, int Ls, const bf16_t* Kh, const bf16_t* Vh,
+                                          const uint8_t* key_pad, int lane) {
+  const int ch = lane & 7, rg = lane >> 3;
+  uint8_t pad[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int pc = min(j0 + rg + 8 * i, Ls - 1);   // clamped: loads stay inside the sentence
+    const int64_t jr = (int64_t)sent * Ls + pc;
+    pad[i] = key_pad[jr];
+    xs.kq[i] = *(const uint4*)(Kh + jr * D + 8 * ch);
+    xs.vq[i] = *(const uint4*)(Vh + jr * D + 8 * ch);
+  }
+  uint32_t ok = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    if (j0 + rg + 8 * i < Ls && !pad[i]) ok |= 1u << i;
+  xs.ok = ok;
+}
+
+__device__ __forceinline__ void attend_shared(const XSeg& xs, const bf16_t* q_lds, int r_lo, int r_hi, int seg, float scale,
                                               float* xacc, float* xml, int lane) {
   const int ch = lane & 7, rg = lane >> 3;
   const uint32_t ones = 0x3f803f80u;   // bf16 (1, 1)
@@ -639,12 +673,9 @@ __device__ __forceinline__ void attend_shared(const bf16_t* q_lds, int r_lo, int
   bool ok[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int pos = j0 + rg + 8 * i;
-    const int pc = min(pos, Ls - 1);   // clamped: loads stay inside the sentence
-    const int64_t jr = (int64_t)sent * Ls + pc;
-    ok[i] = pos < Ls && !key_pad[jr];
-    kq[i] = *(const uint4*)(Kh + jr * D + 8 * ch);
-    vq[i] = *(const uint4*)(Vh + jr * D + 8 * ch);
+    kq[i] = xs.kq[i];
+    vq[i] = xs.vq[i];
+    ok[i] = (xs.ok >> i) & 1;
   }
 #pragma unroll 1
   for (int r = r_lo; r < r_hi; ++r) {
@@ -738,9 +769,8 @@ __device__ __forceinline__ void load_att(char* A, const bf16_t* att, int row0, i
 }
 
 // z[row][col .. col + 3] = bf16(acc + bias) + residual, for the two 16-row halves of a 16-column tile
-__device__ __forceinline__ void store_z(float* zbuf, const char* X, const f32x4_t (&acc)[2], const float* bias, int col,
+__device__ __forceinline__ void store_z(float* zbuf, const char* X, const f32x4_t (&acc)[2], const float4 b, int col,
                                         int row0, int R, int l15) {
-  const float4 b = *(const float4*)(bias + col);
   const float bb[4] = {b.x, b.y, b.z, b.w};
 #pragma unroll
   for (int mi = 0; mi < 2; ++mi) {
@@ -756,6 +786,7 @@ __device__ __forceinline__ void store_z(float* zbuf, const char* X, const f32x4_
   }
 }
 
+template <int V>
 __global__ __launch_bounds__(NTHREADS) void decode_stack_kernel(StackArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int team = blockIdx.x % a.teams_pad, m0 = blockIdx.x / a.teams_pad;   // members of a team: same blockIdx mod 8
@@ -846,7 +877,7 @@ __global__ __launch_bounds__(NTHREADS) void decode_stack_kernel(StackArgs a) {
   __syncthreads();
 
   int stamp_i = 0;
-#define STAMP() do { if (a.stamps && blockIdx.x == 0 && tid_ == 0 && li == min(3, a.n_layers - 1)) a.stamps[stamp_i++] = wall_clock64(); } while (0)
+#define STAMP() do { if (a.stamps && (int)blockIdx.x == a.stamp_block && tid_ == a.stamp_tid && li == min(3, a.n_layers - 1)) a.stamps[stamp_i++] = wall_clock64(); } while (0)
   for (int li = 0; li < a.n_layers; ++li) {
     // Layer addresses are read from the kernel-argument segment (indexing the by-value copy would go through
     // scratch) and declared GLOBAL: from a plain integer cast the compiler could only assume the flat address
@@ -917,36 +948,47 @@ __global__ __launch_bounds__(NTHREADS) void decode_stack_kernel(StackArgs a) {
     WFrag<16> wo;
     {
     IDS();
-    load_w<16>(wo, P.Wo, D, DH * m + 16 * (wave & 3) + l15, 0, g);   // (waves 4..7 load what they do not use: a value defined on one path only is kept in memory)
+    // (waves 4..7 load what they do not use: a value defined on one path only is kept in memory)
+    team_sync(ctx, [&] { load_w<16>(wo, P.Wo, D, DH * m + 16 * (wave & 3) + l15, 0, g); });
     }
-    team_sync(ctx);
     STAMP();  // 3: after sync 1
     // ---- C: output projection columns 64 m .., + residual -> z
     WFrag<16> wc;
     {
     IDS();
+    // (small vectors are requested before the workgroup barrier of their phase: behind it their latency would show)
+    const float4 bias = *(const float4*)(P.bo + DH * m + 16 * (wave & 3) + 4 * g);
     load_att(A, a.att, row0, R, tid);
     __syncthreads();
     if (wave < 4) {
       f32x4_t acc[2] = {f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}};
       mma_rows<16>(acc, wo, A, 1024, 0, l15, g);
-      store_z(a.zbuf, X, acc, P.bo, DH * m + 16 * wave + 4 * g, row0, R, l15);
+      store_z(a.zbuf, X, acc, bias, DH * m + 16 * wave + 4 * g, row0, R, l15);
     }
-    __builtin_amdgcn_sched_barrier(0);
-    load_w<16>(wc, P.Wqc, D, DH * m + 16 * (wave & 3) + l15, 0, g);
     }
     STAMP();  // 4: after C
-    team_sync(ctx);
-    STAMP();  // 5: after sync 2
-    // ---- D: LayerNorm, query projection of head m, attention over the sentence's encoder keys / values
     {
     IDS();
+    team_sync(ctx, [&] { load_w<16>(wc, P.Wqc, D, DH * m + 16 * (wave & 3) + l15, 0, g); });
+    }
+    STAMP();  // 5: after sync 2
+    // ---- D: LayerNorm, query projection of head m, attention over the sentence's encoder keys / values
+    const bool xshared = a.Ls <= XSEG * XSEG_MAX && a.xshare;
+    XSeg xs;
+    {
+    IDS();
+    const float4 b = *(const float4*)(P.bqc + DH * m + 16 * (wave & 3) + 4 * g);
+    if constexpr (V & 1) {   // the wave's first (sentence, segment) pair (or the team's last one again, which nobody then uses)
+      const int s_lo = row0 / a.bm, s_hi = (R - 1) / a.bm, nseg = (a.Ls + XSEG - 1) / XSEG;
+      const int it = min(wave, (s_hi - s_lo + 1) * nseg - 1);
+      xseg_load(xs, s_lo + it / nseg, min(XSEG * (it - (it / nseg) * nseg), a.Ls - 1), a.Ls, P.crossK + DH * m, P.crossV + DH * m,
+                a.src_key_pad, lane);
+    }
     ln_rows(X, a.zbuf, row0, R, P.g1, P.be1, a.row_pad, a.eps, wave, lane);
     __syncthreads();
     if (wave < 4) {
       f32x4_t acc[2] = {f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}};
       mma_rows<16>(acc, wc, X, 1024, 0, l15, g);
-      const float4 b = *(const float4*)(P.bqc + DH * m + 16 * wave + 4 * g);
       const float bb[4] = {b.x, b.y, b.z, b.w};
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi) {
@@ -957,19 +999,26 @@ __global__ __launch_bounds__(NTHREADS) void decode_stack_kernel(StackArgs a) {
     }
     __syncthreads();
     STAMP();  // 6: after LN + cross-q
-    if (a.Ls <= XSEG * XSEG_MAX && a.xshare) {
+    if (xshared) {
       // the team's (sentence, segment) pairs, dealt out to the waves round-robin; then the rows' segments are merged
       IDS();
       const int s_lo = row0 / a.bm, s_hi = (R - 1) / a.bm, nseg = (a.Ls + XSEG - 1) / XSEG;
       const int total = (s_hi - s_lo + 1) * nseg;
       float* xacc = (float*)(smem + L_XACC);
       float* xml = (float*)(smem + L_XML);
+      if (wave < total) {
+        const int sent = s_lo + wave / nseg, seg = wave - (wave / nseg) * nseg;
+        const int r_lo = max(sent * a.bm, row0) - row0, r_hi = min((sent + 1) * a.bm, R) - row0;
+        if constexpr (!(V & 1)) xseg_load(xs, sent, XSEG * seg, a.Ls, P.crossK + DH * m, P.crossV + DH * m, a.src_key_pad, lane);
+        attend_shared(xs, QKV, r_lo, r_hi, seg, a.scale, xacc, xml, lane);
+      }
 #pragma unroll 1
-      for (int it = wave; it < total; it += NTHREADS / 64) {
+      for (int it = wave + NTHREADS / 64; it < total; it += NTHREADS / 64) {
         const int sent = s_lo + it / nseg, seg = it - (it / nseg) * nseg;
         const int r_lo = max(sent * a.bm, row0) - row0, r_hi = min((sent + 1) * a.bm, R) - row0;
-        attend_shared(QKV, r_lo, r_hi, sent, XSEG * seg, seg, a.Ls, a.scale, P.crossK + DH * m, P.crossV + DH * m,
-                      a.src_key_pad, xacc, xml, lane);
+        XSeg xn;
+        xseg_load(xn, sent, XSEG * seg, a.Ls, P.crossK + DH * m, P.crossV + DH * m, a.src_key_pad, lane);
+        attend_shared(xn, QKV, r_lo, r_hi, seg, a.scale, xacc, xml, lane);
       }
       __syncthreads();
       merge_xsegments(xacc, xml, a.att, nseg, row0, R, m, tid);
@@ -998,33 +1047,39 @@ __global__ __launch_bounds__(NTHREADS) void decode_stack_kernel(StackArgs a) {
     WFrag<16> wo2;
     {
     IDS();
-    load_w<16>(wo2, P.Woc, D, DH * m + 16 * (wave & 3) + l15, 0, g);
+    team_sync(ctx, [&] { load_w<16>(wo2, P.Woc, D, DH * m + 16 * (wave & 3) + l15, 0, g); });
     }
-    team_sync(ctx);
     STAMP();  // 8: after sync 3
     // ---- E: second output projection + residual -> z
     WFrag<16> w1[2];
     {
     IDS();
+    const float4 bias = *(const float4*)(P.boc + DH * m + 16 * (wave & 3) + 4 * g);
     load_att(A, a.att, row0, R, tid);
     __syncthreads();
     if (wave < 4) {
       f32x4_t acc[2] = {f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}};
       mma_rows<16>(acc, wo2, A, 1024, 0, l15, g);
-      store_z(a.zbuf, X, acc, P.boc, DH * m + 16 * wave + 4 * g, row0, R, l15);
+      store_z(a.zbuf, X, acc, bias, DH * m + 16 * wave + 4 * g, row0, R, l15);
     }
-    __builtin_amdgcn_sched_barrier(0);
-    // hidden columns 256 m .. 256 m + 255 are 16 tiles: wave w takes tiles 2 w, 2 w + 1
-#pragma unroll
-    for (int t = 0; t < 2; ++t) load_w<16>(w1[t], P.W1, D, 256 * m + 32 * wave + 16 * t + l15, 0, g);
     }
     STAMP();  // 9: after E
-    team_sync(ctx);
+    {
+    IDS();
+    // hidden columns 256 m .. 256 m + 255 are 16 tiles: wave w takes tiles 2 w, 2 w + 1
+    team_sync(ctx, [&] {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) load_w<16>(w1[t], P.W1, D, 256 * m + 32 * wave + 16 * t + l15, 0, g);
+    });
+    }
     STAMP();  // 10: after sync 4
     // ---- F: LayerNorm, hidden slice, ReLU, kept in LDS
     WFrag<8> w2[4];
     {
     IDS();
+    float4 b1v[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) b1v[t] = *(const float4*)(P.b1 + 256 * m + 32 * wave + 16 * t + 4 * g);
     ln_rows(X, a.zbuf, row0, R, P.g2, P.be2, a.row_pad, a.eps, wave, lane);
     __syncthreads();
 #pragma unroll
@@ -1032,7 +1087,7 @@ __global__ __launch_bounds__(NTHREADS) void decode_stack_kernel(StackArgs a) {
       f32x4_t acc[2] = {f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}};
       mma_rows<16>(acc, w1[t], X, 1024, 0, l15, g);
       const int cl = 32 * wave + 16 * t + 4 * g;   // column within the slice
-      const float4 b = *(const float4*)(P.b1 + 256 * m + cl);
+      const float4 b = b1v[t];
       const float bb[4] = {b.x, b.y, b.z, b.w};
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi) {
@@ -1063,17 +1118,18 @@ __global__ __launch_bounds__(NTHREADS) void decode_stack_kernel(StackArgs a) {
         if (rg < R) *(float4*)(a.pbuf + ((int64_t)m * a.R32 + rg) * D + col) = make_float4(acc[mi][0], acc[mi][1], acc[mi][2], acc[mi][3]);
       }
     }
+    }
+    STAMP();  // 12: after G
     // the next layer's q | k | v weights (loaded unconditionally — the last layer re-reads its own — so that the
     // old fragments are dead here and need no registers)
-    __builtin_amdgcn_sched_barrier(0);
     {
+    IDS();
+    team_sync(ctx, [&] {
       const kargs_t qn = kargs + (int64_t)LAYER_FIELDS * min(li + 1, a.n_layers - 1);
       load_w<16>(wq0, GP(const bf16_t, qn[0]), D, qkv_row(wave, m) + l15, 0, g);
       load_w<16>(wq1, GP(const bf16_t, qn[0]), D, qkv_row(8 + (wave & 3), m) + l15, 0, g);
+    });
     }
-    }
-    STAMP();  // 12: after G
-    team_sync(ctx);
     STAMP();  // 13: after sync 5
     if (a.fuse_red) {
       // ---- the partial products summed by every member for all columns, + bias, + residual, LayerNorm -> X
@@ -1186,17 +1242,22 @@ extern "C" int skhip_decode_stack(const int64_t* layers, int n_layers, const int
   { const char* e = getenv("SKHIP_STACK_XSHARE"); a.xshare = !(e && e[0] == '0'); }
   { const char* e = getenv("SKHIP_STACK_FUSERED"); a.fuse_red = !(e && e[0] == '0'); }
   a.stamps = getenv("SKHIP_STACK_STAMPS") ? (long long*)(ws + 512) : nullptr;
+  { const char* e = getenv("SKHIP_STACK_STAMP_BLOCK"); a.stamp_block = e ? atoi(e) : 0; }
+  { const char* e = getenv("SKHIP_STACK_STAMP_TID"); a.stamp_tid = e ? atoi(e) : 0; }
   // the history table rides in LDS when it fits beside the images (history rows of up to 512 positions)
   a.TcP = (Tc + 31) / 32 * 32;
   { const char* e = getenv("SKHIP_STACK_PIPE"); if ((e && e[0] == '0') || L_JT + ROWS * a.TcP * 4 > L_MAX) a.TcP = 0; }
   const int lds_bytes = a.TcP ? L_JT + ROWS * a.TcP * 4 : L_BYTES;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)decode_stack_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, L_MAX);
+    hipError_t e = hipFuncSetAttribute((const void*)decode_stack_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, L_MAX);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)decode_stack_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, L_MAX);
     if (e != hipSuccess) { sk_set_error("skhip_decode_stack: LDS attribute: %s", hipGetErrorString(e)); return SK_ERR_LAUNCH; }
     attr_set = true;
   }
-  hipLaunchKernelGGL(decode_stack_kernel, dim3((unsigned)(a.teams_pad * TEAM)), dim3(NTHREADS), lds_bytes, stream, a);
+  { const char* e = getenv("SKHIP_STACK_VARIANT");
+    if (e && e[0] == '1') hipLaunchKernelGGL(decode_stack_kernel<1>, dim3((unsigned)(a.teams_pad * TEAM)), dim3(NTHREADS), lds_bytes, stream, a);
+    else hipLaunchKernelGGL(decode_stack_kernel<0>, dim3((unsigned)(a.teams_pad * TEAM)), dim3(NTHREADS), lds_bytes, stream, a); }
   SK_CHECK_LAUNCH("skhip_decode_stack");
   return SK_OK;
 }
