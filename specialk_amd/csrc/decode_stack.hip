@@ -466,7 +466,7 @@ __device__ __forceinline__ void self_issue(KVStage& st, const SelfRows& sr, cons
                                            const bf16_t* Vh, int wave, int s, int lane) {
   const int ch = lane & 7, rg = lane >> 3;
   const int total = sr.ns[0] + sr.ns[1];
-  const int sc = min(s, total - 1);   // past the end: the last stage once more
+  const int sc = max(min(s, total - 1), 0);   // past the end: the last stage once more
   const int p = sc >= sr.ns[0] ? 1 : 0, w = sc - (p ? sr.ns[0] : 0);
   uint32_t ok = 0;
 #pragma unroll
@@ -575,11 +575,7 @@ __device__ __forceinline__ void self_compute(const KVStage& st, SelfState& S, co
 }
 
 // att: the team's first row of the attention buffer, head m's columns; Kc / Vc: the layer's caches at head m's columns
-__device__ __forceinline__ void self_attend_pipe(const int32_t* JT, int TcP, bf16_t* QKV, const int32_t* cur_len, int Tc,
-                                                 bf16_t* Kc, bf16_t* Vc, bf16_t* att, int row0, int R, float scale,
-                                                 int wave, int lane) {
-  const int ch = lane & 7, rg = lane >> 3;
-  SelfRows sr;
+__device__ __forceinline__ void self_rows(SelfRows& sr, const int32_t* cur_len, int Tc, int row0, int R, int wave) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int rgl = row0 + wave + 8 * i;
@@ -590,6 +586,14 @@ __device__ __forceinline__ void self_attend_pipe(const int32_t* JT, int TcP, bf1
     const int nmax = max(sr.n[2 * p], sr.n[2 * p + 1]);
     sr.ns[p] = nmax > 0 ? max((nmax - 1 + 31) >> 5, 1) : 0;   // (a row with the newest position only still takes a stage)
   }
+}
+
+// A: stage 0, already requested (self_issue(A, .., 0, ..) — before the q | k | v product of the layer, which hides its
+// trip to memory; with no rows at all, total == 0, it holds the loads of a clamped address and is dropped)
+__device__ __forceinline__ void self_attend_pipe(KVStage& A, const SelfRows& sr, const int32_t* JT, int TcP, bf16_t* QKV,
+                                                 bf16_t* Kc, bf16_t* Vc, bf16_t* att, int row0, int R, float scale,
+                                                 int wave, int lane) {
+  const int ch = lane & 7, rg = lane >> 3;
   const int total = sr.ns[0] + sr.ns[1];
   if (total == 0) return;
   // the newest position joins the caches: groups 0 / 1 store the key / value chunks
@@ -609,9 +613,7 @@ __device__ __forceinline__ void self_attend_pipe(const int32_t* JT, int TcP, bf1
 #pragma unroll
     for (int e = 0; e < 8; ++e) S.acc[x][e] = 0.f;
   }
-  KVStage A, B;
-  self_issue(A, sr, JT, TcP, Kc, Vc, wave, 0, lane);
-  __builtin_amdgcn_sched_barrier(0);
+  KVStage B;
 #pragma unroll 1
   for (int s = 0; s < total; s += 2) {
     self_issue(B, sr, JT, TcP, Kc, Vc, wave, s + 1, lane);
@@ -786,7 +788,7 @@ __device__ __forceinline__ void store_z(float* zbuf, const char* X, const f32x4_
   }
 }
 
-template <int V>
+template <bool PIPE>   // self-attention by self_attend_pipe() over the history table in LDS / by attend()
 __global__ __launch_bounds__(NTHREADS) void decode_stack_kernel(StackArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int team = blockIdx.x % a.teams_pad, m0 = blockIdx.x / a.teams_pad;   // members of a team: same blockIdx mod 8
@@ -841,7 +843,7 @@ __global__ __launch_bounds__(NTHREADS) void decode_stack_kernel(StackArgs a) {
     *(uint4*)(X + r * 1024 + ((lane ^ (r & 15)) << 4)) = o.v;
   }
   // history table: per thread 8 entries at a time, their two dependent loads in flight together
-  if (a.TcP) {
+  if constexpr (PIPE) {
     int32_t* JT = (int32_t*)(smem + L_JT);
     const int n_ent = ROWS * a.TcP;
 #pragma unroll 1
@@ -876,6 +878,11 @@ __global__ __launch_bounds__(NTHREADS) void decode_stack_kernel(StackArgs a) {
   }
   __syncthreads();
 
+  SelfRows sr;
+  if constexpr (PIPE) {
+    IDS();
+    self_rows(sr, a.cur_len, a.Tc, row0, R, wave);
+  }
   int stamp_i = 0;
 #define STAMP() do { if (a.stamps && (int)blockIdx.x == a.stamp_block && tid_ == a.stamp_tid && li == min(3, a.n_layers - 1)) a.stamps[stamp_i++] = wall_clock64(); } while (0)
   for (int li = 0; li < a.n_layers; ++li) {
@@ -895,6 +902,12 @@ __global__ __launch_bounds__(NTHREADS) void decode_stack_kernel(StackArgs a) {
     }
     STAMP();  // 0
     // ---- A: q | k | v of head m for the 32 rows
+    KVStage st0;
+    if constexpr (PIPE) {
+      IDS();
+      self_issue(st0, sr, (const int32_t*)(smem + L_JT), a.TcP, P.Kc + DH * m, P.Vc + DH * m, wave, 0, lane);
+      __builtin_amdgcn_sched_barrier(0);
+    }
     {
     IDS();
 #pragma unroll
@@ -916,9 +929,9 @@ __global__ __launch_bounds__(NTHREADS) void decode_stack_kernel(StackArgs a) {
     STAMP();  // 1: after A
     // ---- B: self-attention of head m (wave w: the team's rows w, w + 8, w + 16, w + 24, two at a time), appending
     // the new key / value
-    if (a.TcP) {
+    if constexpr (PIPE) {
       IDS();
-      self_attend_pipe((const int32_t*)(smem + L_JT), a.TcP, QKV, a.cur_len, a.Tc, P.Kc + DH * m, P.Vc + DH * m,
+      self_attend_pipe(st0, sr, (const int32_t*)(smem + L_JT), a.TcP, QKV, P.Kc + DH * m, P.Vc + DH * m,
                        a.att + (int64_t)row0 * D + DH * m, row0, R, a.scale, wave, lane);
     } else
     {
@@ -978,7 +991,7 @@ __global__ __launch_bounds__(NTHREADS) void decode_stack_kernel(StackArgs a) {
     {
     IDS();
     const float4 b = *(const float4*)(P.bqc + DH * m + 16 * (wave & 3) + 4 * g);
-    if constexpr (V & 1) {   // the wave's first (sentence, segment) pair (or the team's last one again, which nobody then uses)
+    {   // the wave's first (sentence, segment) pair (or the team's last one again, which nobody then uses)
       const int s_lo = row0 / a.bm, s_hi = (R - 1) / a.bm, nseg = (a.Ls + XSEG - 1) / XSEG;
       const int it = min(wave, (s_hi - s_lo + 1) * nseg - 1);
       xseg_load(xs, s_lo + it / nseg, min(XSEG * (it - (it / nseg) * nseg), a.Ls - 1), a.Ls, P.crossK + DH * m, P.crossV + DH * m,
@@ -1009,7 +1022,6 @@ __global__ __launch_bounds__(NTHREADS) void decode_stack_kernel(StackArgs a) {
       if (wave < total) {
         const int sent = s_lo + wave / nseg, seg = wave - (wave / nseg) * nseg;
         const int r_lo = max(sent * a.bm, row0) - row0, r_hi = min((sent + 1) * a.bm, R) - row0;
-        if constexpr (!(V & 1)) xseg_load(xs, sent, XSEG * seg, a.Ls, P.crossK + DH * m, P.crossV + DH * m, a.src_key_pad, lane);
         attend_shared(xs, QKV, r_lo, r_hi, seg, a.scale, xacc, xml, lane);
       }
 #pragma unroll 1
@@ -1250,14 +1262,13 @@ extern "C" int skhip_decode_stack(const int64_t* layers, int n_layers, const int
   const int lds_bytes = a.TcP ? L_JT + ROWS * a.TcP * 4 : L_BYTES;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)decode_stack_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, L_MAX);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)decode_stack_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, L_MAX);
+    hipError_t e = hipFuncSetAttribute((const void*)decode_stack_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, L_MAX);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)decode_stack_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, L_BYTES);
     if (e != hipSuccess) { sk_set_error("skhip_decode_stack: LDS attribute: %s", hipGetErrorString(e)); return SK_ERR_LAUNCH; }
     attr_set = true;
   }
-  { const char* e = getenv("SKHIP_STACK_VARIANT");
-    if (e && e[0] == '1') hipLaunchKernelGGL(decode_stack_kernel<1>, dim3((unsigned)(a.teams_pad * TEAM)), dim3(NTHREADS), lds_bytes, stream, a);
-    else hipLaunchKernelGGL(decode_stack_kernel<0>, dim3((unsigned)(a.teams_pad * TEAM)), dim3(NTHREADS), lds_bytes, stream, a); }
+  if (a.TcP) hipLaunchKernelGGL(decode_stack_kernel<true>, dim3((unsigned)(a.teams_pad * TEAM)), dim3(NTHREADS), lds_bytes, stream, a);
+  else hipLaunchKernelGGL(decode_stack_kernel<false>, dim3((unsigned)(a.teams_pad * TEAM)), dim3(NTHREADS), lds_bytes, stream, a);
   SK_CHECK_LAUNCH("skhip_decode_stack");
   return SK_OK;
 }
