@@ -153,6 +153,28 @@ __device__ __forceinline__ void mma_rows(f32x4_t (&acc)[2], const WFrag<NK>& f, 
   }
 }
 
+// The same over NT weight tiles at once: an activation fragment is read from LDS once and multiplies all NT tiles.
+// (Tile by tile every tile re-reads the whole image, and with eight waves at it the LDS port — 128 bytes a clock —
+// sets the pace: four tiles of the [32][256] hidden slice per wave are 512 KB a phase, 2 us.)
+template <int NT, int NK>
+__device__ __forceinline__ void mma_rows_tiles(f32x4_t (&acc)[NT][2], const WFrag<NK> (&f)[NT], const char* A, int row_bytes,
+                                               int kc0, int l15, int g) {
+  const char* a0 = A + l15 * row_bytes;
+  const char* a1 = A + (16 + l15) * row_bytes;
+#pragma unroll
+  for (int kk = 0; kk < NK; ++kk) {
+    const int off = ((kc0 + 4 * kk + g) ^ l15) << 4;
+    const bf16x8_t fa0 = *(const bf16x8_t*)(a0 + off);
+    const bf16x8_t fa1 = *(const bf16x8_t*)(a1 + off);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[t].w[kk], fa0, acc[t][0], 0, 0, 0);
+      acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[t].w[kk], fa1, acc[t][1], 0, 0, 0);
+    }
+    if ((kk & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 __device__ __forceinline__ float round_bf16(float v) { return bf16_to_f32(f32_to_bf16(v)); }
 
 // four consecutive bf16 of the swizzled [32][512] image: row r, columns col .. col + 3 (col % 4 == 0)
@@ -175,8 +197,10 @@ __device__ __forceinline__ uint2 pack4(const float (&v)[4]) {
 // w + 24 — with 20 rows per team every wave then has two or three of them instead of five waves four each; a lane
 // owns 8 consecutive columns; same arithmetic as add_ln_fwd_kernel of layernorm.hip).  Rows beyond the team's last
 // one are left as they are in X: the products run over all 32 image rows and their results are never stored.
+// after_loads(): requests of the phase that may trail the rows' own (a prefetch for later in the phase).
+template <class F>
 __device__ __forceinline__ void ln_rows(char* X, const float* z, int row0, int R, const float* gamma, const float* beta,
-                                        const uint8_t* row_pad, float eps, int wave, int lane) {
+                                        const uint8_t* row_pad, float eps, int wave, int lane, F&& after_loads) {
   float4 zz[4][2];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {   // all rows' loads in flight together
@@ -187,13 +211,18 @@ __device__ __forceinline__ void ln_rows(char* X, const float* z, int row0, int R
   const float4* gp = (const float4*)(gamma + 8 * lane);
   const float4* bp = (const float4*)(beta + 8 * lane);
   const float4 g0 = gp[0], g1 = gp[1], b0 = bp[0], b1 = bp[1];
+  uint8_t pads[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) pads[i] = row_pad[min(row0 + wave + 8 * i, R - 1)];
+  __builtin_amdgcn_sched_barrier(0);
+  after_loads();
+  __builtin_amdgcn_sched_barrier(0);
   const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
   const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int r = wave + 8 * i;
     if (row0 + r >= R) break;   // wave-uniform
-    const int rg = row0 + r;
     const float4 z0 = zz[i][0], z1 = zz[i][1];
     const float v[8] = {z0.x, z0.y, z0.z, z0.w, z1.x, z1.y, z1.z, z1.w};
     float sum = 0.f;
@@ -204,12 +233,16 @@ __device__ __forceinline__ void ln_rows(char* X, const float* z, int row0, int R
 #pragma unroll
     for (int j = 0; j < 8; ++j) { const float c = v[j] - mean; sq += c * c; }
     const float rstd = 1.0f / sqrtf(wave_sum(sq) / (float)D + eps);
-    const bool pad = row_pad[rg] != 0;
+    const bool pad = pads[i] != 0;
     Vec16<bf16_t> o;
 #pragma unroll
     for (int j = 0; j < 8; ++j) o.set(j, pad ? 0.f : (v[j] - mean) * rstd * gg[j] + bb[j]);
     *(uint4*)(X + r * 1024 + ((lane ^ (r & 15)) << 4)) = o.v;
   }
+}
+__device__ __forceinline__ void ln_rows(char* X, const float* z, int row0, int R, const float* gamma, const float* beta,
+                                        const uint8_t* row_pad, float eps, int wave, int lane) {
+  ln_rows(X, z, row0, R, gamma, beta, row_pad, eps, wave, lane, [] {});
 }
 
 // ---- the same LayerNorm fed from the team's 8 partial second feed-forward products: every member sums ALL columns of
@@ -824,11 +857,11 @@ __global__ __launch_bounds__(NTHREADS) void decode_stack_kernel(StackArgs a) {
   // q | k | v of head m are 12 column tiles of 16: tile t = (which = t / 4, sub = t % 4); wave w takes tile w, and
   // waves 0..3 tile 8 + w as well
   auto qkv_row = [](int t, int m) { return (t >> 2) * D + DH * m + 16 * (t & 3); };
-  WFrag<16> wq0, wq1;
+  WFrag<16> wq[2];
   {
   IDS();
-  load_w<16>(wq0, GP(const bf16_t, kargs[0]), D, qkv_row(wave, m) + l15, 0, g);
-  load_w<16>(wq1, GP(const bf16_t, kargs[0]), D, qkv_row(8 + (wave & 3), m) + l15, 0, g);
+  load_w<16>(wq[0], GP(const bf16_t, kargs[0]), D, qkv_row(wave, m) + l15, 0, g);
+  load_w<16>(wq[1], GP(const bf16_t, kargs[0]), D, qkv_row(8 + (wave & 3), m) + l15, 0, g);
   // embedding of the newest token of each row: word_emb[tok] + pos_tab[pos]
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -902,7 +935,16 @@ __global__ __launch_bounds__(NTHREADS) void decode_stack_kernel(StackArgs a) {
     }
     STAMP();  // 0
     // ---- A: q | k | v of head m for the 32 rows
+    // (loads return in the order of their issue: whatever a phase needs early is requested BEFORE a long-latency
+    // prefetch, never behind it)
     KVStage st0;
+    float4 bqv[2];
+    {
+      IDS();
+      bqv[0] = *(const float4*)(P.bqkv + qkv_row(wave, m) + 4 * g);
+      bqv[1] = *(const float4*)(P.bqkv + qkv_row(8 + (wave & 3), m) + 4 * g);
+      __builtin_amdgcn_sched_barrier(0);
+    }
     if constexpr (PIPE) {
       IDS();
       self_issue(st0, sr, (const int32_t*)(smem + L_JT), a.TcP, P.Kc + DH * m, P.Vc + DH * m, wave, 0, lane);
@@ -910,13 +952,17 @@ __global__ __launch_bounds__(NTHREADS) void decode_stack_kernel(StackArgs a) {
     }
     {
     IDS();
+    // (both tiles in one pass over the image; waves 4..7 multiply a second tile too and drop it)
+    f32x4_t accq[2][2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) accq[u][0] = accq[u][1] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    mma_rows_tiles<2, 16>(accq, wq, X, 1024, 0, l15, g);
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       if (u == 1 && wave >= 4) break;
       const int t = u == 0 ? wave : 8 + wave;
-      f32x4_t acc[2] = {f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}};
-      mma_rows<16>(acc, u == 0 ? wq0 : wq1, X, 1024, 0, l15, g);
-      const float4 b = *(const float4*)(P.bqkv + qkv_row(t, m) + 4 * g);
+      const f32x4_t (&acc)[2] = accq[u];
+      const float4 b = bqv[u];
       const float bb[4] = {b.x, b.y, b.z, b.w};
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi) {
@@ -991,13 +1037,13 @@ __global__ __launch_bounds__(NTHREADS) void decode_stack_kernel(StackArgs a) {
     {
     IDS();
     const float4 b = *(const float4*)(P.bqc + DH * m + 16 * (wave & 3) + 4 * g);
-    {   // the wave's first (sentence, segment) pair (or the team's last one again, which nobody then uses)
+    ln_rows(X, a.zbuf, row0, R, P.g1, P.be1, a.row_pad, a.eps, wave, lane, [&] {
+      // the wave's first (sentence, segment) pair (or the team's last one again, which nobody then uses)
       const int s_lo = row0 / a.bm, s_hi = (R - 1) / a.bm, nseg = (a.Ls + XSEG - 1) / XSEG;
       const int it = min(wave, (s_hi - s_lo + 1) * nseg - 1);
-      xseg_load(xs, s_lo + it / nseg, min(XSEG * (it - (it / nseg) * nseg), a.Ls - 1), a.Ls, P.crossK + DH * m, P.crossV + DH * m,
+      xseg_load(xs, s_lo + it / nseg, XSEG * (it - (it / nseg) * nseg), a.Ls, P.crossK + DH * m, P.crossV + DH * m,
                 a.src_key_pad, lane);
-    }
-    ln_rows(X, a.zbuf, row0, R, P.g1, P.be1, a.row_pad, a.eps, wave, lane);
+    });
     __syncthreads();
     if (wave < 4) {
       f32x4_t acc[2] = {f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}};
@@ -1092,7 +1138,10 @@ __global__ __launch_bounds__(NTHREADS) void decode_stack_kernel(StackArgs a) {
     float4 b1v[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) b1v[t] = *(const float4*)(P.b1 + 256 * m + 32 * wave + 16 * t + 4 * g);
-    ln_rows(X, a.zbuf, row0, R, P.g2, P.be2, a.row_pad, a.eps, wave, lane);
+    // G operands: output columns 64 w + 16 t .. (rows of W2), K range 256 m .. 256 m + 255; one of the four tiles
+    // behind the LayerNorm's own loads, the others as the hidden tiles' weights die and leave them registers
+    ln_rows(X, a.zbuf, row0, R, P.g2, P.be2, a.row_pad, a.eps, wave, lane,
+            [&] { load_w<8>(w2[0], P.W2, F, 64 * wave + l15, 256 * m, g); });
     __syncthreads();
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
@@ -1108,26 +1157,32 @@ __global__ __launch_bounds__(NTHREADS) void decode_stack_kernel(StackArgs a) {
                             fmaxf(acc[mi][3] + bb[3], 0.f)};
         *(uint2*)(HS + r * 512 + (((cl >> 3) ^ (r & 15)) << 4) + (cl & 7) * 2) = pack4(v);
       }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- G operands: output columns 64 w + 16 t .. (rows of W2), K range 256 m .. 256 m + 255
+      __builtin_amdgcn_sched_barrier(0);
+      if (t == 0) {
 #pragma unroll
-    for (int t = 0; t < 4; ++t) load_w<8>(w2[t], P.W2, F, 64 * wave + 16 * t + l15, 256 * m, g);
+        for (int t2 = 1; t2 < 3; ++t2) load_w<8>(w2[t2], P.W2, F, 64 * wave + 16 * t2 + l15, 256 * m, g);
+      } else {
+        load_w<8>(w2[3], P.W2, F, 64 * wave + 48 + l15, 256 * m, g);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
     }
     __syncthreads();
     STAMP();  // 11: after LN + F
     // ---- G: partial second feed-forward product over this member's 256 hidden columns -> pbuf[m]
     {
     IDS();
+    f32x4_t acc[4][2];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t][0] = acc[t][1] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    mma_rows_tiles<4, 8>(acc, w2, HS, 512, 0, l15, g);
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      f32x4_t acc[2] = {f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}};
-      mma_rows<8>(acc, w2[t], HS, 512, 0, l15, g);
       const int col = 64 * wave + 16 * t + 4 * g;
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi) {
         const int rg = row0 + 16 * mi + l15;
-        if (rg < R) *(float4*)(a.pbuf + ((int64_t)m * a.R32 + rg) * D + col) = make_float4(acc[mi][0], acc[mi][1], acc[mi][2], acc[mi][3]);
+        if (rg < R) *(float4*)(a.pbuf + ((int64_t)m * a.R32 + rg) * D + col) = make_float4(acc[t][mi][0], acc[t][mi][1], acc[t][mi][2], acc[t][mi][3]);
       }
     }
     }
@@ -1138,8 +1193,8 @@ __global__ __launch_bounds__(NTHREADS) void decode_stack_kernel(StackArgs a) {
     IDS();
     team_sync(ctx, [&] {
       const kargs_t qn = kargs + (int64_t)LAYER_FIELDS * min(li + 1, a.n_layers - 1);
-      load_w<16>(wq0, GP(const bf16_t, qn[0]), D, qkv_row(wave, m) + l15, 0, g);
-      load_w<16>(wq1, GP(const bf16_t, qn[0]), D, qkv_row(8 + (wave & 3), m) + l15, 0, g);
+      load_w<16>(wq[0], GP(const bf16_t, qn[0]), D, qkv_row(wave, m) + l15, 0, g);
+      load_w<16>(wq[1], GP(const bf16_t, qn[0]), D, qkv_row(8 + (wave & 3), m) + l15, 0, g);
     });
     }
     STAMP();  // 13: after sync 5
