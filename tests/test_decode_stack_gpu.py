@@ -35,9 +35,10 @@ def batch(n, lo, hi, vocab, seed):
     return seq.to(DEV), pos.to(DEV)
 
 
-@pytest.mark.parametrize("n_sent,n_layers", [(12, 2), (128, 1), (7, 3), (1, 2)])
+@pytest.mark.parametrize("n_sent,n_layers", [(12, 2), (128, 1), (7, 3), (1, 2), (141, 1)])
 def test_stack_step_matches_op_by_op(n_sent, n_layers):
-    """n_sent x 5 beam rows: 60 (two teams, the second with 28 rows), 640 (twenty full teams), 35, 5 (one sentence).  Every step's
+    """n_sent x 5 beam rows: 60, 640 (32 teams of 20 rows: waves 0..3 with a third row), 35, 5 (one sentence),
+    705 (teams of 23 and 22 rows).  Every step's
     decoder output within 2e-2 of the op-by-op path's (bf16 storage, different summation order in the second
     feed-forward product), over 12 steps of growing history with re-parented beams."""
     from specialk_amd.decode import BeamDecoder
