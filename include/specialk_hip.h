@@ -388,6 +388,17 @@ int skhip_beam_update(const float* new_scores, const int32_t* prev, const int32_
                       const int32_t* hist_in, int32_t* hist_out, int n_sent, int bm, int Tc, int max_len,
                       int pad_id, int eos_id, void* stream);
 
+/* skhip_beam_topk_stats followed by skhip_beam_update in ONE launch (a workgroup per sentence, a wave per beam row):
+ * Beam.advance and the bookkeeping around it as cited at those two (lib/transformer/Beam.py:46-79,
+ * lib/transformer/Translator.py:113-168), with the same arguments, bytes and results — new_scores / prev / new_tok
+ * [n_sent][bm] are still written — and `scores` both the beams' scores going in and the updated state.  Inside a
+ * replayed graph a step then crosses one kernel boundary for this work instead of three.                          */
+int skhip_beam_step(const float* logits, const float* stats, float* new_scores, int32_t* prev, int32_t* new_tok,
+                    void* ws, float* scores, int32_t* ys, int32_t* ks, int32_t* done, int32_t* length,
+                    int32_t* n_done, int32_t* cur_len, int64_t* tok, int64_t* pos, uint8_t* row_pad,
+                    uint8_t* pad_hist, const int32_t* hist_in, int32_t* hist_out, int n_sent, int bm, int64_t V,
+                    int first_step, int Tc, int max_len, int pad_id, int eos_id, void* stream);
+
 /* Reorder a cache after a beam step: dst[r] = src[src_row[r]] for rows of `row_elems`
  * elements (replaces re-building dec_seq from back-pointers every step, Beam.py:90-110,
  * and the index_select compaction, Translator.py:65-101).                                  */

@@ -23,7 +23,7 @@ EXPORTS = [
     "skhip_attn_bwd", "skhip_attn_varlen_fwd", "skhip_attn_varlen_bwd", "skhip_add_ln_fwd", "skhip_add_ln_bwd_ws_floats", "skhip_add_ln_bwd", "skhip_embed_fwd",
     "skhip_embed_bwd", "skhip_pack_plan", "skhip_xent_fwd_bwd", "skhip_adam_multi", "skhip_cast_multi", "skhip_cast2d_multi", "skhip_convert",
     "skhip_decode_attn", "skhip_beam_topk_ws_bytes", "skhip_beam_topk", "skhip_beam_update", "skhip_gather_rows",
-    "skhip_decode_stack_ws_bytes", "skhip_decode_stack", "skhip_beam_topk_stats",
+    "skhip_decode_stack_ws_bytes", "skhip_decode_stack", "skhip_beam_topk_stats", "skhip_beam_step",
     "skhip_softmax_rows", "skhip_conv_windows", "skhip_cnn_head", "skhip_collate", "skhip_set_reserved_cus",
 ]
 
@@ -75,6 +75,7 @@ def load():
     lib.skhip_beam_topk.argtypes = [c_p] * 6 + [c_int, c_int, c_i64, c_int, c_int, c_p]
     lib.skhip_beam_topk_stats.argtypes = [c_p] * 7 + [c_int, c_int, c_i64, c_int, c_p]
     lib.skhip_beam_update.argtypes = [c_p] * 16 + [c_int] * 6 + [c_p]
+    lib.skhip_beam_step.argtypes = [c_p] * 19 + [c_int, c_int, c_i64] + [c_int] * 5 + [c_p]
     lib.skhip_decode_stack_ws_bytes.argtypes = [c_int]
     lib.skhip_decode_stack_ws_bytes.restype = c_i64
     lib.skhip_decode_stack.argtypes = [c_p, c_int] + [c_p] * 11 + [c_i64] + [c_int] * 8 + [c_f32, c_f32, c_int, c_p]
@@ -442,6 +443,23 @@ def beam_update(new_scores, prev, new_tok, scores, ys, ks, done, length, n_done,
                                   _ptr(pad_hist), _ptr(hist_in), _ptr(hist_out), n_sent, bm, Tc, max_len, pad_id, eos_id,
                                   _stream())
     _check(rc, "skhip_beam_update")
+
+
+def beam_step(logits, stats, out, scores, ys, ks, done, length, n_done, cur_len, tok, pos, row_pad, pad_hist, hist_in,
+              hist_out, n_sent, bm, first_step, Tc, max_len, pad_id, eos_id):
+    """beam_topk_stats + beam_update in one launch; out = (new_scores, prev, new_tok) as for beam_topk_stats."""
+    lib = load()
+    V = logits.shape[-1]
+    new_scores, prev, new_tok = out
+    assert logits.dtype == stats.dtype == torch.float32 and stats.numel() >= n_sent * bm * ((V + 63) // 64) * 2
+    assert done.dtype == length.dtype == n_done.dtype == cur_len.dtype == torch.int32
+    assert tok.dtype == pos.dtype == torch.int64 and row_pad.dtype == pad_hist.dtype == torch.uint8
+    ws = workspace(int(lib.skhip_beam_topk_ws_bytes(n_sent, bm, V)))
+    rc = lib.skhip_beam_step(_ptr(logits), _ptr(stats), _ptr(new_scores), _ptr(prev), _ptr(new_tok), _ptr(ws), _ptr(scores),
+                             _ptr(ys), _ptr(ks), _ptr(done), _ptr(length), _ptr(n_done), _ptr(cur_len), _ptr(tok), _ptr(pos),
+                             _ptr(row_pad), _ptr(pad_hist), _ptr(hist_in), _ptr(hist_out), n_sent, bm, V, int(first_step),
+                             Tc, max_len, pad_id, eos_id, _stream())
+    _check(rc, "skhip_beam_step")
 
 
 def decode_stack_ws_bytes(R):

@@ -295,12 +295,10 @@ __global__ __launch_bounds__(256) void beam_row_topk_kernel(const float* __restr
 // chunks are read, 64 logits at a time, instead of the whole row twice.  Same (value, index) order as above.
 constexpr int STAT_SLOTS = 16;   // chunk statistics per lane: rows of up to 64 * 64 * 16 = 65 536 tokens
 template <int KC>
-__global__ __launch_bounds__(64) void beam_row_topk_stats_kernel(const float* __restrict__ logits,
-                                                                 const float2* __restrict__ stats,
-                                                                 const float* __restrict__ scores_in,
-                                                                 float* __restrict__ cand_val, int32_t* __restrict__ cand_idx,
-                                                                 int bm, int64_t V, int first_step) {
-  const int row = blockIdx.x, beam = row % bm, lane = threadIdx.x;
+__device__ __forceinline__ void row_topk_stats(const float* logits, const float2* stats, const float* scores_in,
+                                               float* cand_val, int32_t* cand_idx, int bm, int64_t V, int first_step,
+                                               int row, int lane) {
+  const int beam = row % bm;
   float* cv = cand_val + (int64_t)row * bm;
   int32_t* ci = cand_idx + (int64_t)row * bm;
   if (first_step && beam != 0) {
@@ -401,13 +399,19 @@ __global__ __launch_bounds__(64) void beam_row_topk_stats_kernel(const float* __
   }
 }
 
+template <int KC>
+__global__ __launch_bounds__(64) void beam_row_topk_stats_kernel(const float* __restrict__ logits,
+                                                                 const float2* __restrict__ stats,
+                                                                 const float* __restrict__ scores_in,
+                                                                 float* __restrict__ cand_val, int32_t* __restrict__ cand_idx,
+                                                                 int bm, int64_t V, int first_step) {
+  row_topk_stats<KC>(logits, stats, scores_in, cand_val, cand_idx, bm, V, first_step, blockIdx.x, threadIdx.x);
+}
+
 // Pass B: one wave per sentence merges its bm*bm row candidates into the new beam,
 // ordered like flat_beam_lk.topk(size, 0, True, True) with flat id = beam*V + token.
-__global__ __launch_bounds__(64) void beam_merge_kernel(const float* __restrict__ cand_val,
-                                                        const int32_t* __restrict__ cand_idx,
-                                                        float* __restrict__ scores_out, int32_t* __restrict__ prev_out,
-                                                        int32_t* __restrict__ tok_out, int bm, int64_t V) {
-  const int sent = blockIdx.x, lane = threadIdx.x;
+__device__ __forceinline__ void beam_merge(const float* cand_val, const int32_t* cand_idx, float* scores_out,
+                                           int32_t* prev_out, int32_t* tok_out, int bm, int64_t V, int sent, int lane) {
   const int n = bm * bm;  // <= 256
   float v[4];
   int id[4];  // index into the sentence's candidate list; flat order = (beam, rank) and within a
@@ -448,6 +452,13 @@ __global__ __launch_bounds__(64) void beam_merge_kernel(const float* __restrict_
   }
 }
 
+__global__ __launch_bounds__(64) void beam_merge_kernel(const float* __restrict__ cand_val,
+                                                        const int32_t* __restrict__ cand_idx,
+                                                        float* __restrict__ scores_out, int32_t* __restrict__ prev_out,
+                                                        int32_t* __restrict__ tok_out, int bm, int64_t V) {
+  beam_merge(cand_val, cand_idx, scores_out, prev_out, tok_out, bm, V, blockIdx.x, threadIdx.x);
+}
+
 // ------------------------------------------------------------------ row gather
 template <int VB>  // bytes per access
 __global__ __launch_bounds__(256) void gather_rows_kernel(const char* __restrict__ src, char* __restrict__ dst,
@@ -472,16 +483,25 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const char* __restrict
 //   sentence finishes (length[s] = t, done[s] = 1, *n_done += 1) when its best beam's token is EOS;
 //   history table re-parented: hist_out[r][0..t) = hist_in[s*bm + prev[s][b]][0..t), hist_out[r][t] = r;
 //   inputs of the next step: tok[r], pos[r] = t + 1, row_pad[r] and pad_hist[r][t] = (token is PAD), cur_len[r] = t + 1.
-__global__ __launch_bounds__(64) void beam_update_kernel(const float* __restrict__ new_scores, const int32_t* __restrict__ prev,
-                                                         const int32_t* __restrict__ new_tok, float* __restrict__ scores,
-                                                         int32_t* __restrict__ ys, int32_t* __restrict__ ks,
-                                                         int32_t* __restrict__ done, int32_t* __restrict__ length,
-                                                         int32_t* __restrict__ n_done, int32_t* __restrict__ cur_len,
-                                                         int64_t* __restrict__ tok, int64_t* __restrict__ pos,
-                                                         uint8_t* __restrict__ row_pad, uint8_t* __restrict__ pad_hist,
-                                                         const int32_t* __restrict__ hist_in, int32_t* __restrict__ hist_out,
-                                                         int n_sent, int bm, int Tc, int max_len, int pad_id, int eos_id) {
-  const int r = blockIdx.x, lane = threadIdx.x;
+struct BeamState {
+  float* scores;
+  int32_t *ys, *ks, *done, *length, *n_done, *cur_len;
+  int64_t *tok, *pos;
+  uint8_t *row_pad, *pad_hist;
+  const int32_t* hist_in;
+  int32_t* hist_out;
+  int n_sent, bm, Tc, max_len, pad_id, eos_id;
+};
+
+__device__ __forceinline__ void beam_update_row(const float* new_scores, const int32_t* prev, const int32_t* new_tok,
+                                                const BeamState& st, int r, int lane) {
+  float* scores = st.scores;
+  int32_t *ys = st.ys, *ks = st.ks, *done = st.done, *length = st.length, *n_done = st.n_done, *cur_len = st.cur_len;
+  int64_t *tok = st.tok, *pos = st.pos;
+  uint8_t *row_pad = st.row_pad, *pad_hist = st.pad_hist;
+  const int32_t* hist_in = st.hist_in;
+  int32_t* hist_out = st.hist_out;
+  const int n_sent = st.n_sent, bm = st.bm, Tc = st.Tc, max_len = st.max_len, pad_id = st.pad_id, eos_id = st.eos_id;
   const int s = r / bm, b = r - s * bm;
   const int t = cur_len[r];
   if (t < 1 || t > max_len) return;  // past the last step (a replayed graph may overshoot): nothing to do
@@ -504,6 +524,27 @@ __global__ __launch_bounds__(64) void beam_update_kernel(const float* __restrict
       if (w == eos_id) { length[s] = t; done[s] = 1; atomicAdd(n_done, 1); }
     }
   }
+}
+
+__global__ __launch_bounds__(64) void beam_update_kernel(const float* __restrict__ new_scores, const int32_t* __restrict__ prev,
+                                                         const int32_t* __restrict__ new_tok, BeamState st) {
+  beam_update_row(new_scores, prev, new_tok, st, blockIdx.x, threadIdx.x);
+}
+
+// The three passes of a step in one launch: a workgroup per sentence, a wave per beam row.  The row candidates and
+// the merged beam travel through global memory as in the separate launches (same bytes, same results); what goes
+// is two of the three kernel boundaries of a step, some 10 us each inside a replayed graph.
+template <int KC>
+__global__ __launch_bounds__(1024) void beam_step_kernel(const float* logits, const float2* stats, float* cand_val,
+                                                         int32_t* cand_idx, float* new_scores, int32_t* prev,
+                                                         int32_t* new_tok, int64_t V, int first_step, BeamState st) {
+  const int sent = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int row = sent * st.bm + wave;
+  row_topk_stats<KC>(logits, stats, st.scores, cand_val, cand_idx, st.bm, V, first_step, row, lane);
+  __syncthreads();
+  if (wave == 0) beam_merge(cand_val, cand_idx, new_scores, prev, new_tok, st.bm, V, sent, lane);
+  __syncthreads();
+  beam_update_row(new_scores, prev, new_tok, st, row, lane);
 }
 
 }  // namespace
@@ -629,9 +670,38 @@ extern "C" int skhip_beam_update(const float* new_scores, const int32_t* prev, c
   if (n_sent == 0) return SK_OK;
   SK_CHECK_ARG(new_scores && prev && new_tok && scores && ys && ks && done && length && n_done && cur_len && tok && pos &&
                row_pad && pad_hist && hist_in && hist_out && hist_in != hist_out, "skhip_beam_update: null or aliased pointer");
-  hipLaunchKernelGGL(beam_update_kernel, dim3((unsigned)(n_sent * bm)), dim3(64), 0, stream, new_scores, prev, new_tok, scores,
-                     ys, ks, done, length, n_done, cur_len, tok, pos, row_pad, pad_hist, hist_in, hist_out, n_sent, bm, Tc,
-                     max_len, pad_id, eos_id);
+  const BeamState st{scores, ys, ks, done, length, n_done, cur_len, tok, pos, row_pad, pad_hist, hist_in, hist_out,
+                     n_sent, bm, Tc, max_len, pad_id, eos_id};
+  hipLaunchKernelGGL(beam_update_kernel, dim3((unsigned)(n_sent * bm)), dim3(64), 0, stream, new_scores, prev, new_tok, st);
   SK_CHECK_LAUNCH("skhip_beam_update");
+  return SK_OK;
+}
+
+extern "C" int skhip_beam_step(const float* logits, const float* stats, float* new_scores, int32_t* prev, int32_t* new_tok,
+                               void* ws, float* scores, int32_t* ys, int32_t* ks, int32_t* done, int32_t* length,
+                               int32_t* n_done, int32_t* cur_len, int64_t* tok, int64_t* pos, uint8_t* row_pad,
+                               uint8_t* pad_hist, const int32_t* hist_in, int32_t* hist_out, int n_sent, int bm, int64_t V,
+                               int first_step, int Tc, int max_len, int pad_id, int eos_id, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SK_CHECK_ARG(bm >= 1 && bm <= 16, "skhip_beam_step: beam size %d not in 1..16", bm);
+  SK_CHECK_ARG(V >= bm && V <= 64 * 64 * STAT_SLOTS, "skhip_beam_step: V=%lld not in bm..65536", (long long)V);
+  SK_CHECK_ARG(n_sent >= 0 && Tc >= 1 && max_len >= 1, "skhip_beam_step: bad shape");
+  if (n_sent == 0) return SK_OK;
+  SK_CHECK_ARG(logits && stats && new_scores && prev && new_tok && ws && (uintptr_t)stats % 8 == 0 && scores && ys && ks &&
+               done && length && n_done && cur_len && tok && pos && row_pad && pad_hist && hist_in && hist_out &&
+               hist_in != hist_out && new_scores != scores, "skhip_beam_step: null, misaligned or aliased pointer");
+  float* cv = (float*)ws;
+  int32_t* ci = (int32_t*)(cv + (int64_t)n_sent * bm * bm);
+  const BeamState st{scores, ys, ks, done, length, n_done, cur_len, tok, pos, row_pad, pad_hist, hist_in, hist_out,
+                     n_sent, bm, Tc, max_len, pad_id, eos_id};
+  const dim3 grid((unsigned)n_sent), block((unsigned)(64 * bm));
+#define BEAM_F(KC) hipLaunchKernelGGL((beam_step_kernel<KC>), grid, block, 0, stream, logits, (const float2*)stats, cv, ci, new_scores, prev, new_tok, V, first_step, st)
+  if (bm <= 1) BEAM_F(1);
+  else if (bm <= 2) BEAM_F(2);
+  else if (bm <= 4) BEAM_F(4);
+  else if (bm <= 8) BEAM_F(8);
+  else BEAM_F(16);
+#undef BEAM_F
+  SK_CHECK_LAUNCH("skhip_beam_step");
   return SK_OK;
 }

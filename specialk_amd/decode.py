@@ -183,6 +183,9 @@ class BeamDecoder:
         if use_stats:
             logits_buf = torch.empty((R, V), dtype=torch.float32, device=dev)
             gen_stats = torch.empty((R, (V + 63) // 64, 2), dtype=torch.float32, device=dev)
+        # (tests that force or trace a step's choices sit between the top-k and the update: they keep the separate launches)
+        fused_step = (use_stats and self.forced is None and self.trace is None
+                      and os.environ.get("SK_DECODE_FUSED_STEP", "1") != "0")
         step_no = [0]
 
         def step(first, cur):
@@ -218,6 +221,12 @@ class BeamDecoder:
                 # the top-k then reads those and the few chunks that can hold a best token, not every row twice
                 L.gemm(L.GEMM_NT, x, gen_w, R, V, d, d, d, out=logits_buf, ldc=V, aux=gen_stats, epilogue=L.EPI_ROWSTATS,
                        split_k=False)
+                if fused_step:  # top-k, merge and state update in one launch
+                    L.beam_step(logits_buf, gen_stats, (new_scores, prev, new_tok), scores, ys, ks, done, length, n_done,
+                                cur_len, tok, pos, row_pad, pad_hist, hist[cur], hist[cur ^ 1], n, bm, first, Tc, Tmax,
+                                Constants.PAD, Constants.EOS)
+                    step_no[0] += 1
+                    return
                 L.beam_topk_stats(logits_buf, gen_stats, scores, n, bm, first, out=(new_scores, prev, new_tok))
             else:  # fp32 models keep expf and the reference's bits
                 logits = L.gemm(L.GEMM_NT, x, gen_w, R, V, d, d, d, out_dtype=torch.float32)

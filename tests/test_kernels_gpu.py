@@ -723,6 +723,60 @@ def test_beam_topk_from_generator_statistics(L, V, bm, rows_of):
         assert (so2 - so).abs().max().item() <= 2e-5
 
 
+@pytest.mark.parametrize("V,bm,n_sent", [(35000, 5, 128), (1003, 5, 7), (200, 16, 2), (4096, 1, 3)])
+def test_beam_step_equals_topk_then_update(L, V, bm, n_sent):
+    """skhip_beam_step against skhip_beam_topk_stats + skhip_beam_update on the same state: every output and every
+    piece of state bit for bit, at the first step (beam 0 only) and at a later one with finished sentences, EOS on
+    a best beam, padding tokens and re-parented histories."""
+    g = torch.Generator().manual_seed(31 * V + bm)
+    R, d, Tc, Tmax, PAD, EOS = n_sent * bm, 512, 12, 11, 0, 3
+    x = rnd((R, d), torch.bfloat16, g).to(DEV)
+    W = (rnd((V, d), torch.bfloat16, g) * 0.2).to(DEV)
+    logits = torch.empty((R, V), dtype=torch.float32, device=DEV)
+    stats = torch.empty((R, (V + 63) // 64, 2), dtype=torch.float32, device=DEV)
+    L.gemm(L.GEMM_NT, x, W, R, V, d, d, d, out=logits, ldc=V, aux=stats, epilogue=L.EPI_ROWSTATS, split_k=False)
+    logits[0, EOS] = 50.0   # sentence 0 ends at this step
+    if R > bm:
+        logits[bm, PAD] = 50.0   # a padding token on a best beam
+    # (statistics refreshed for the edited rows)
+    pad = torch.full((R, stats.shape[1] * 64), float("-inf"), dtype=torch.float32, device=DEV)
+    pad[:, :V] = logits
+    ch = pad.view(R, -1, 64)
+    stats[:, :, 0] = ch.max(2).values
+    stats[:, :, 1] = torch.exp(ch - stats[:, :, 0:1]).sum(2)
+    i32 = dict(dtype=torch.int32, device=DEV)
+    for first, t in ((True, 1), (False, 6)):
+        def state():
+            gs = torch.Generator().manual_seed(t)
+            st = dict(scores=(-torch.rand(n_sent, bm, generator=gs) * 5).to(DEV), ys=torch.zeros((Tmax + 1, n_sent, bm), **i32),
+                      ks=torch.zeros((Tmax, n_sent, bm), **i32), done=torch.zeros(n_sent, **i32),
+                      length=torch.full((n_sent,), Tmax, **i32), n_done=torch.zeros(1, **i32),
+                      cur_len=torch.full((R,), t, **i32), tok=torch.zeros(R, dtype=torch.int64, device=DEV),
+                      pos=torch.zeros(R, dtype=torch.int64, device=DEV), row_pad=torch.zeros(R, dtype=torch.uint8, device=DEV),
+                      pad_hist=torch.zeros((R, Tc), dtype=torch.uint8, device=DEV),
+                      hist_in=torch.randint(0, R, (R, Tc), generator=gs, dtype=torch.int32).to(DEV),
+                      hist_out=torch.full((R, Tc), -1, **i32))
+            st["scores"][0, 1:] = -30.0   # sentence 0's best candidate comes from beam 0, whose best token is EOS
+            if n_sent > 2:
+                st["done"][2] = 1   # a sentence that finished earlier keeps its scores
+                st["n_done"][0] = 1
+            return st
+        a, b = state(), state()
+        outs = [tuple(torch.empty((n_sent, bm), dtype=dt, device=DEV) for dt in (torch.float32, torch.int32, torch.int32))
+                for _ in range(2)]
+        L.beam_topk_stats(logits, stats, a["scores"], n_sent, bm, first, outs[0])
+        L.beam_update(*outs[0], a["scores"], a["ys"], a["ks"], a["done"], a["length"], a["n_done"], a["cur_len"], a["tok"],
+                      a["pos"], a["row_pad"], a["pad_hist"], a["hist_in"], a["hist_out"], n_sent, bm, Tc, Tmax, PAD, EOS)
+        L.beam_step(logits, stats, outs[1], b["scores"], b["ys"], b["ks"], b["done"], b["length"], b["n_done"], b["cur_len"],
+                    b["tok"], b["pos"], b["row_pad"], b["pad_hist"], b["hist_in"], b["hist_out"], n_sent, bm, first, Tc, Tmax,
+                    PAD, EOS)
+        for u, v in zip(outs[0], outs[1]):
+            assert torch.equal(u, v), (V, bm, first)
+        for k in a:
+            assert torch.equal(a[k], b[k]), (k, V, bm, first)
+        assert a["done"][0].item() == 1 and a["length"][0].item() == t   # the EOS case was exercised
+
+
 def test_gather_rows(L):
     g = torch.Generator().manual_seed(6)
     for dtype, elems in ((torch.float32, 96), (torch.bfloat16, 100), (torch.bfloat16, 64)):
