@@ -156,9 +156,10 @@ __device__ __forceinline__ void mma_rows(f32x4_t (&acc)[2], const WFrag<NK>& f, 
 // The same over NT weight tiles at once: an activation fragment is read from LDS once and multiplies all NT tiles.
 // (Tile by tile every tile re-reads the whole image, and with eight waves at it the LDS port — 128 bytes a clock —
 // sets the pace: four tiles of the [32][256] hidden slice per wave are 512 KB a phase, 2 us.)
-template <int NT, int NK>
+// every4(kk), kk = 3, 7, ..: a place for requests that use the registers of the weight fragments consumed so far.
+template <int NT, int NK, class H>
 __device__ __forceinline__ void mma_rows_tiles(f32x4_t (&acc)[NT][2], const WFrag<NK> (&f)[NT], const char* A, int row_bytes,
-                                               int kc0, int l15, int g) {
+                                               int kc0, int l15, int g, H&& every4) {
   const char* a0 = A + l15 * row_bytes;
   const char* a1 = A + (16 + l15) * row_bytes;
 #pragma unroll
@@ -171,8 +172,17 @@ __device__ __forceinline__ void mma_rows_tiles(f32x4_t (&acc)[NT][2], const WFra
       acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[t].w[kk], fa0, acc[t][0], 0, 0, 0);
       acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[t].w[kk], fa1, acc[t][1], 0, 0, 0);
     }
-    if ((kk & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+    if ((kk & 3) == 3) {
+      __builtin_amdgcn_sched_barrier(0);
+      every4(kk);
+      __builtin_amdgcn_sched_barrier(0);
+    }
   }
+}
+template <int NT, int NK>
+__device__ __forceinline__ void mma_rows_tiles(f32x4_t (&acc)[NT][2], const WFrag<NK> (&f)[NT], const char* A, int row_bytes,
+                                               int kc0, int l15, int g) {
+  mma_rows_tiles<NT, NK>(acc, f, A, row_bytes, kc0, l15, g, [](int) {});
 }
 
 __device__ __forceinline__ float round_bf16(float v) { return bf16_to_f32(f32_to_bf16(v)); }
@@ -1139,14 +1149,22 @@ __global__ __launch_bounds__(NTHREADS) void decode_stack_kernel(StackArgs a) {
 #pragma unroll
     for (int t = 0; t < 2; ++t) b1v[t] = *(const float4*)(P.b1 + 256 * m + 32 * wave + 16 * t + 4 * g);
     // G operands: output columns 64 w + 16 t .. (rows of W2), K range 256 m .. 256 m + 255; one of the four tiles
-    // behind the LayerNorm's own loads, the others as the hidden tiles' weights die and leave them registers
+    // behind the LayerNorm's own loads, the others as the hidden product consumes its weight fragments and leaves
+    // them registers (both hidden tiles in one pass over the image)
     ln_rows(X, a.zbuf, row0, R, P.g2, P.be2, a.row_pad, a.eps, wave, lane,
             [&] { load_w<8>(w2[0], P.W2, F, 64 * wave + l15, 256 * m, g); });
     __syncthreads();
+    f32x4_t acch[2][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) acch[t][0] = acch[t][1] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    mma_rows_tiles<2, 16>(acch, w1, X, 1024, 0, l15, g, [&](int kk) {
+      if (kk == 3) load_w<8>(w2[1], P.W2, F, 64 * wave + 16 + l15, 256 * m, g);
+      if (kk == 7) load_w<8>(w2[2], P.W2, F, 64 * wave + 32 + l15, 256 * m, g);
+      if (kk == 11) load_w<8>(w2[3], P.W2, F, 64 * wave + 48 + l15, 256 * m, g);
+    });
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-      f32x4_t acc[2] = {f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}};
-      mma_rows<16>(acc, w1[t], X, 1024, 0, l15, g);
+      const f32x4_t (&acc)[2] = acch[t];
       const int cl = 32 * wave + 16 * t + 4 * g;   // column within the slice
       const float4 b = b1v[t];
       const float bb[4] = {b.x, b.y, b.z, b.w};
@@ -1157,14 +1175,6 @@ __global__ __launch_bounds__(NTHREADS) void decode_stack_kernel(StackArgs a) {
                             fmaxf(acc[mi][3] + bb[3], 0.f)};
         *(uint2*)(HS + r * 512 + (((cl >> 3) ^ (r & 15)) << 4) + (cl & 7) * 2) = pack4(v);
       }
-      __builtin_amdgcn_sched_barrier(0);
-      if (t == 0) {
-#pragma unroll
-        for (int t2 = 1; t2 < 3; ++t2) load_w<8>(w2[t2], P.W2, F, 64 * wave + 16 * t2 + l15, 256 * m, g);
-      } else {
-        load_w<8>(w2[3], P.W2, F, 64 * wave + 48 + l15, 256 * m, g);
-      }
-      __builtin_amdgcn_sched_barrier(0);
     }
     }
     __syncthreads();
