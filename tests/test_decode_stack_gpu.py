@@ -99,9 +99,31 @@ def test_stack_encoder_attention_forms_agree(monkeypatch):
     assert float((a - b).abs().max() / b.abs().max()) <= 2e-2
 
 
+@pytest.mark.parametrize("switch", ["SKHIP_STACK_PIPE", "SKHIP_STACK_FUSERED"])
+def test_stack_fallback_forms_match_op_by_op(monkeypatch, switch):
+    """The stack keeps two older forms behind switches: self-attention in 64-position sweeps by attend() (what
+    history rows too long for the LDS table take; SKHIP_STACK_PIPE=0) and the feed-forward partial products summed by
+    columns with a sixth team barrier (SKHIP_STACK_FUSERED=0).  Each against the op-by-op path over 40 steps, the
+    search's choices forced to be the same: every step's decoder output within 2e-2."""
+    from specialk_amd.decode import BeamDecoder
+    m = build(2, len_max=48)
+    src, pos = batch(9, 5, 20, 1000, 21)
+    ref = BeamDecoder(m, 5, 40, use_graph=False, use_stack=False)
+    ref.trace = []
+    ref.run(src, pos, 1)
+    monkeypatch.setenv(switch, "0")
+    got = BeamDecoder(m, 5, 40, use_graph=False, use_stack=True)
+    got.trace, got.forced = [], [t[1:] for t in ref.trace]
+    got.run(src, pos, 1)
+    assert got.used_stack and len(got.trace) == len(ref.trace) >= 30
+    for a, b in zip(got.trace, ref.trace):
+        xa, xb = a[0].float(), b[0].float()
+        assert float((xa - xb).abs().max() / xb.abs().max()) <= 2e-2
+
+
 def test_stack_long_histories_match_op_by_op():
-    """Histories of up to 150 positions (three 64-position sweeps of the self-attention, the length of the benchmark's
-    decode leg) and source sentences of up to 70 positions (three segments of the encoder attention): every step's
+    """Histories of up to 150 positions (five 32-position stages of the self-attention pipeline, the length of the
+    benchmark's decode leg) and source sentences of up to 70 positions (three segments of the encoder attention): every step's
     decoder output of the one-launch stack within 2e-2 of the op-by-op path's, the search's choices forced to be the
     same."""
     from specialk_amd.decode import BeamDecoder
