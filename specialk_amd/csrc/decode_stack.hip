@@ -10,13 +10,14 @@
 // rows in LDS; a projection is split over the members by output columns (member m: head m of q / k / v and of
 // the attention, columns 64 m .. 64 m + 63 of the 512-wide outputs, columns 256 m .. of the hidden layer), so a
 // member streams one eighth of every weight matrix — straight from global memory into MFMA operand registers,
-// requested a phase ahead — and the members exchange their 32-row slices through global memory with a team
-// barrier (six per layer).  The second feed-forward product is split over the members along K instead: a
-// member multiplies its own slice of the hidden layer, which never leaves its LDS.  Teams never wait for each
-// other.  All summation orders are fixed: results are bit-reproducible.
+// requested while the member waits at the team barrier before their use — and the members exchange their 32-row
+// slices through global memory with a team barrier (five per layer).  The second feed-forward product is split
+// over the members along K instead: a member multiplies its own slice of the hidden layer, which never leaves its
+// LDS, and every member adds the eight partial products up inside the LayerNorm that follows.  Teams never wait
+// for each other.  All summation orders are fixed: results are bit-reproducible.
 //
 // Team barrier: every wave waits for its stores (they are then in the L2), workgroup barrier, one atomic
-// increment, a BOUNDED spin on the counter (a member that gives up raises the error word and stops waiting from
+// increment, the next phase's weight requests, a BOUNDED spin on the counter (a member that gives up raises the error word and stops waiting from
 // then on, so every wave reaches the end of the kernel whatever happens), workgroup barrier, invalidation of the
 // CU's L1.  The members of a team have the same block index modulo 8, which the dispatcher places on ONE XCD:
 // they share an L2, so the exchange needs no L2 write-back or invalidation (agent-scope fences cost 20-80 us
