@@ -116,7 +116,16 @@ def _ptr(t):
     return t.data_ptr()
 
 
+# The current stream's handle, per launch: torch.cuda.current_stream() builds a Stream object and resolves the device
+# three times over (7 us a call, a quarter of the host time of a short op-by-op pass); the raw accessors behind it take
+# well under one.
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_raw_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def _stream():
+    if _raw_stream is not None and _raw_device is not None:
+        return _raw_stream(_raw_device())
     return torch.cuda.current_stream().cuda_stream
 
 
@@ -126,8 +135,17 @@ _workspaces = {}
 def workspace(nbytes=64 << 20, device=None):
     """Persistent scratch per device and stream (split-K slabs, LayerNorm partials, beam candidates):
     kernels enqueued on different streams may run concurrently and must not share scratch."""
-    device = torch.device("cuda", torch.cuda.current_device()) if device is None else device
-    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    if device is None and _raw_stream is not None and _raw_device is not None:
+        index = _raw_device()
+        key = (index, _raw_stream(index))
+        ws = _workspaces.get(key)
+        if ws is not None and ws.numel() >= nbytes:
+            return ws
+        device = torch.device("cuda", index)
+    else:
+        device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        index = device.index if device.index is not None else torch.cuda.current_device()
+        key = (index, torch.cuda.current_stream(device).cuda_stream)
     ws = _workspaces.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(max(nbytes, 64 << 20), dtype=torch.uint8, device=device)

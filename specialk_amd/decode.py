@@ -16,6 +16,7 @@ a sentence ends when its TOP beam emits EOS, other beams keep extending past EOS
 penalty; step 1 only expands beam 0.
 """
 import os
+import time
 
 import numpy as np
 import torch
@@ -81,6 +82,15 @@ class BeamDecoder:
         if Tmax >= n_pos:
             raise IndexError(f"max_token_seq_len={Tmax} needs a position table of {Tmax + 1} rows, have {n_pos}")
 
+        # SK_DECODE_TIMES=1: wall-clock of the call's parts (with a device synchronisation at each boundary) in self.times
+        marks = [] if os.environ.get("SK_DECODE_TIMES") else None
+
+        def mark(name):
+            if marks is not None:
+                torch.cuda.synchronize(dev)
+                marks.append((name, time.perf_counter()))
+
+        mark("start")
         was_training = model.training
         model.eval()
         enc_out, *_ = model.encoder(src_seq, src_pos)
@@ -127,12 +137,12 @@ class BeamDecoder:
         V = gen_w.shape[0]
         word_emb, pos_tab = dec.tgt_word_emb.weight.detach(), dec.position_enc.weight.detach()
 
-        # q | k | v of the self-attention in one projection (weights stacked once per call)
-        qkv_w = [torch.cat([self._w(l.slf_attn.w_qs.weight, dt), self._w(l.slf_attn.w_ks.weight, dt),
-                            self._w(l.slf_attn.w_vs.weight, dt)], 0).contiguous() for l in layers]
-        qkv_b = [torch.cat([l.slf_attn.w_qs.bias.detach(), l.slf_attn.w_ks.bias.detach(),
-                            l.slf_attn.w_vs.bias.detach()]).float().contiguous() for l in layers]
+        # q | k | v of the self-attention in one projection (weights stacked once per call, all layers in one copy)
         nq, nk, nv = H * dk, H * dk, H * dv
+        qkv_w = torch.cat([self._w(p, dt) for l in layers for p in (l.slf_attn.w_qs.weight, l.slf_attn.w_ks.weight,
+                                                                    l.slf_attn.w_vs.weight)], 0).view(NL, nq + nk + nv, d)
+        qkv_b = torch.cat([p.detach() for l in layers for p in (l.slf_attn.w_qs.bias, l.slf_attn.w_ks.bias,
+                                                                l.slf_attn.w_vs.bias)]).float().view(NL, nq + nk + nv)
 
         def proj(x, lin, out=None, ldc=None, relu=False):
             w = self._w(lin.weight, dt)
@@ -155,7 +165,7 @@ class BeamDecoder:
                 """The kernel reads its weight matrices fragment-major, [rows / 16][K / 32][64 lanes][8]: matrices of
                 one shape are permuted together (one copy kernel per shape, every call: the optimiser updates weights
                 in place without touching version counters, so nothing here may be cached)."""
-                W = torch.stack(mats)
+                W = mats if torch.is_tensor(mats) else torch.stack(mats)
                 n_, N_, K_ = W.shape
                 return W.view(n_, N_ // 16, 16, K_ // 32, 4, 8).permute(0, 1, 3, 4, 2, 5).contiguous()
 
@@ -242,11 +252,13 @@ class BeamDecoder:
             L.beam_update(new_scores, prev, new_tok, scores, ys, ks, done, length, n_done, cur_len, tok, pos, row_pad,
                           pad_hist, hist[cur], hist[cur ^ 1], n, bm, Tc, Tmax, Constants.PAD, Constants.EOS)
 
+        mark("encoder + set-up")
         step(True, 0)  # step 1 expands beam 0 only (Beam.py:51-54)
         steps, cur = 1, 1
         graph = None
         if self.use_graph and Tmax >= 3:
             graph = self._capture_pair(step, cur, dev)
+        mark("first step + graph capture")
         # the host looks at the finished-sentence count every fourth step only: a step past the end changes nothing
         # (finished sentences keep their state) and costs less than a pipeline drain per step
         while steps < Tmax:
@@ -259,6 +271,7 @@ class BeamDecoder:
                 steps += 1
             if (steps % 4 <= 1 or steps == Tmax) and int(n_done.item()) == n:
                 break
+        mark("steps")
         del graph
         self.last_steps = steps
         if stack and int(stack_ws[4 * L.STACK_ERR_WORD:4 * L.STACK_ERR_WORD + 4].view(torch.int32).item()) != 0:
@@ -266,19 +279,26 @@ class BeamDecoder:
         if was_training:
             model.train()
 
-        # hypotheses: walk the back-pointers on the host (Beam.get_hypothesis, Beam.py:103-110)
+        # hypotheses: walk the back-pointers on the host (Beam.get_hypothesis, Beam.py:103-110), all sentences and
+        # ranks in step: one gather per position instead of one Python iteration per token
         ys_h, ks_h = ys[: steps + 1].cpu().numpy(), ks[:steps].cpu().numpy()
         len_h, scores_h = length.cpu().numpy(), scores
-        all_hyp, all_scores = [], []
-        for s in range(n):
-            T_s = int(min(len_h[s], steps))
-            hyps = []
-            for k0 in range(min(n_best, bm)):
-                k, hyp = k0, []
-                for j in range(T_s - 1, -1, -1):
-                    hyp.append(int(ys_h[j + 1, s, k]))
-                    k = int(ks_h[j, s, k])
-                hyps.append(hyp[::-1])
-            all_hyp.append(hyps)
-            all_scores.append(scores_h[s, :n_best])
+        nb = min(n_best, bm)
+        T_all = np.minimum(len_h, steps).astype(np.int64)                 # [n]
+        T_max = int(T_all.max()) if n else 0
+        ys_f, ks_f = ys_h.reshape(steps + 1, n * bm), ks_h.reshape(steps, n * bm)
+        base = (np.arange(n, dtype=np.int64) * bm)[:, None]
+        k = np.tile(np.arange(nb, dtype=np.int64)[None, :], (n, 1))       # [n][nb]: beam of rank k0 at the last step
+        toks = np.zeros((max(T_max, 1), n, nb), dtype=np.int64)
+        all_live = bool((T_all == T_max).all())
+        for j in range(T_max - 1, -1, -1):
+            at = base + k
+            toks[j] = ys_f[j + 1].take(at)
+            k = ks_f[j].take(at) if all_live else np.where((j < T_all)[:, None], ks_f[j].take(at), k)
+        toks = toks.transpose(1, 2, 0)                                    # [n][nb][T]: sentences shorter than T_max keep their prefix
+        all_hyp = [[toks[s, r, :T_all[s]].tolist() for r in range(nb)] for s in range(n)]
+        all_scores = list(scores_h[:, :n_best].unbind(0))
+        mark("hypotheses")
+        if marks is not None:
+            self.times = {b[0]: b[1] - a[1] for a, b in zip(marks, marks[1:])}
         return all_hyp, all_scores
