@@ -143,7 +143,7 @@ class Encoder(nn.Module):
         if self.check_ids:
             _check_ids(src_seq, src_pos, self.src_word_emb.num_embeddings, self.position_enc.num_embeddings)
         key_pad = src_seq.eq(Constants.PAD).to(torch.uint8).contiguous()  # (B, Ls); also the pad-row bitmap
-        x = ops.EmbedFn.apply(src_seq, src_pos, self.src_word_emb.weight, self.position_enc.weight,
+        x = ops.call(ops.EmbedFn, src_seq, src_pos, self.src_word_emb.weight, self.position_enc.weight,
                               self.compute_dtype)
         attns = []
         for layer in self.layer_stack:
@@ -159,7 +159,7 @@ class Encoder(nn.Module):
     def forward_packed(self, src_seq, src_pos, plan):
         """Encoder over the packed rows of `plan` (no padding rows anywhere): -> (n_src_tokens, d)."""
         flat = plan.idx
-        x = ops.EmbedFn.apply(src_seq.reshape(-1)[flat], src_pos.reshape(-1)[flat], self.src_word_emb.weight,
+        x = ops.call(ops.EmbedFn, src_seq.reshape(-1)[flat], src_pos.reshape(-1)[flat], self.src_word_emb.weight,
                               self.position_enc.weight, self.compute_dtype)
         for layer in self.layer_stack:
             x, _ = layer.forward_2d(x, plan.B, plan.max_len, off=plan.off)
@@ -188,7 +188,7 @@ class Decoder(nn.Module):
             _check_ids(tgt_seq, tgt_pos, self.tgt_word_emb.num_embeddings, self.position_enc.num_embeddings)
         key_pad = tgt_seq.eq(Constants.PAD).to(torch.uint8).contiguous()
         src_key_pad = src_seq.eq(Constants.PAD).to(torch.uint8).contiguous()
-        x = ops.EmbedFn.apply(tgt_seq, tgt_pos, self.tgt_word_emb.weight, self.position_enc.weight,
+        x = ops.call(ops.EmbedFn, tgt_seq, tgt_pos, self.tgt_word_emb.weight, self.position_enc.weight,
                               self.compute_dtype)
         enc2d = enc_output.reshape(B * Ls, -1)
         if enc2d.dtype != self.compute_dtype:
@@ -212,7 +212,7 @@ class Decoder(nn.Module):
     def forward_packed(self, tgt_seq, tgt_pos, plan, enc_packed, src_plan):
         """Decoder over packed target rows attending to packed encoder rows: -> (n_tgt_tokens, d)."""
         flat = plan.idx
-        x = ops.EmbedFn.apply(tgt_seq.reshape(-1)[flat], tgt_pos.reshape(-1)[flat], self.tgt_word_emb.weight,
+        x = ops.call(ops.EmbedFn, tgt_seq.reshape(-1)[flat], tgt_pos.reshape(-1)[flat], self.tgt_word_emb.weight,
                               self.position_enc.weight, self.compute_dtype)
         kv_all, pres = ops.cross_kv(enc_packed, [layer.enc_attn for layer in self.layer_stack])
         for li, layer in enumerate(self.layer_stack):

@@ -45,7 +45,7 @@ class MultiHeadAttention(nn.Module):
                    key_pad=key_pad, causal=bool(causal), dense_mask=dense_mask,
                    scale=1.0 / float(self.attention.temperature),
                    p_attn=self.attention.dropout.p if training else 0.0, want_attn=want_attn, kv_pre=kv_pre)
-        out, attn = ops.MHAFn.apply(q_in, kv_in, self.w_qs.weight, self.w_qs.bias, self.w_ks.weight, self.w_ks.bias,
+        out, attn = ops.call(ops.MHAFn, q_in, kv_in, self.w_qs.weight, self.w_qs.bias, self.w_ks.weight, self.w_ks.bias,
                                     self.w_vs.weight, self.w_vs.bias, self.fc.weight, self.fc.bias, cfg)
         y = ops.add_ln(out, q_in, self.layer_norm.weight, self.layer_norm.bias, row_pad, self.layer_norm.eps,
                        self.dropout.p if training else 0.0, res_feeds_x=True)
@@ -91,7 +91,7 @@ class PositionwiseFeedForward(nn.Module):
         self.dropout = nn.Dropout(dropout)
 
     def forward_2d(self, x, row_pad=None):
-        y = ops.FFNFn.apply(x, self.w_1.weight, self.w_1.bias, self.w_2.weight, self.w_2.bias)
+        y = ops.call(ops.FFNFn, x, self.w_1.weight, self.w_1.bias, self.w_2.weight, self.w_2.bias)
         return ops.add_ln(y, x, self.layer_norm.weight, self.layer_norm.bias, row_pad, self.layer_norm.eps,
                           self.dropout.p if self.training else 0.0, res_feeds_x=True)
 
