@@ -60,6 +60,17 @@ class BeamDecoder:
             step(False, cur ^ 1)
         return graph
 
+    def _prepared(self, layers, dtype, dev):
+        """Weights in the forms a call needs (stacked q | k | v, fragment-major matrices), kept between calls.  They are
+        current as long as no optimiser update of this package has run (ops.weights_epoch: its kernel changes parameters
+        without touching torch's version counters) and no parameter's version counter has moved (every other way of
+        writing a parameter).  SK_DECODE_KEEP_WEIGHTS=0: rebuilt every call."""
+        key = (ops.weights_epoch(), dtype, dev, tuple((id(p), p._version) for l in layers for p in l.parameters()))
+        held = getattr(self, "_prep", None)
+        if held is None or held[0] != key or os.environ.get("SK_DECODE_KEEP_WEIGHTS", "1") == "0":
+            held = self._prep = (key, {})
+        return held[1]
+
     def _w(self, p, dtype):
         w = ops.compute_weight(p, dtype)
         return w.reshape(w.shape[0], -1)
@@ -137,12 +148,16 @@ class BeamDecoder:
         V = gen_w.shape[0]
         word_emb, pos_tab = dec.tgt_word_emb.weight.detach(), dec.position_enc.weight.detach()
 
-        # q | k | v of the self-attention in one projection (weights stacked once per call, all layers in one copy)
+        # q | k | v of the self-attention in one projection: weights stacked, all layers in one copy, and kept from
+        # call to call while the weights stay what they were (see _prepared)
         nq, nk, nv = H * dk, H * dk, H * dv
-        qkv_w = torch.cat([self._w(p, dt) for l in layers for p in (l.slf_attn.w_qs.weight, l.slf_attn.w_ks.weight,
-                                                                    l.slf_attn.w_vs.weight)], 0).view(NL, nq + nk + nv, d)
-        qkv_b = torch.cat([p.detach() for l in layers for p in (l.slf_attn.w_qs.bias, l.slf_attn.w_ks.bias,
-                                                                l.slf_attn.w_vs.bias)]).float().view(NL, nq + nk + nv)
+        prep = self._prepared(layers, dt, dev)
+        if "qkv_w" not in prep:
+            prep["qkv_w"] = torch.cat([self._w(p, dt) for l in layers for p in (l.slf_attn.w_qs.weight, l.slf_attn.w_ks.weight,
+                                                                               l.slf_attn.w_vs.weight)], 0).view(NL, nq + nk + nv, d)
+            prep["qkv_b"] = torch.cat([p.detach() for l in layers for p in (l.slf_attn.w_qs.bias, l.slf_attn.w_ks.bias,
+                                                                            l.slf_attn.w_vs.bias)]).float().view(NL, nq + nk + nv)
+        qkv_w, qkv_b = prep["qkv_w"], prep["qkv_b"]
 
         def proj(x, lin, out=None, ldc=None, relu=False):
             w = self._w(lin.weight, dt)
@@ -163,17 +178,18 @@ class BeamDecoder:
 
             def frag_major(mats):
                 """The kernel reads its weight matrices fragment-major, [rows / 16][K / 32][64 lanes][8]: matrices of
-                one shape are permuted together (one copy kernel per shape, every call: the optimiser updates weights
-                in place without touching version counters, so nothing here may be cached)."""
+                one shape are permuted together (one copy kernel per shape)."""
                 W = mats if torch.is_tensor(mats) else torch.stack(mats)
                 n_, N_, K_ = W.shape
                 return W.view(n_, N_ // 16, 16, K_ // 32, 4, 8).permute(0, 1, 3, 4, 2, 5).contiguous()
 
-            fm_qkv = frag_major(qkv_w)
-            fm_sq = frag_major([self._w(p, dt) for l in layers for p in (l.slf_attn.fc.weight, l.enc_attn.w_qs.weight,
-                                                                          l.enc_attn.fc.weight)])
-            fm_w1 = frag_major([self._w(l.pos_ffn.w_1.weight, dt) for l in layers])
-            fm_w2 = frag_major([self._w(l.pos_ffn.w_2.weight, dt) for l in layers])
+            if "fm_qkv" not in prep:
+                prep["fm_qkv"] = frag_major(qkv_w)
+                prep["fm_sq"] = frag_major([self._w(p, dt) for l in layers for p in (l.slf_attn.fc.weight, l.enc_attn.w_qs.weight,
+                                                                                      l.enc_attn.fc.weight)])
+                prep["fm_w1"] = frag_major([self._w(l.pos_ffn.w_1.weight, dt) for l in layers])
+                prep["fm_w2"] = frag_major([self._w(l.pos_ffn.w_2.weight, dt) for l in layers])
+            fm_qkv, fm_sq, fm_w1, fm_w2 = prep["fm_qkv"], prep["fm_sq"], prep["fm_w1"], prep["fm_w2"]
             rows, keep = [], []
             for li, l in enumerate(layers):
                 s_, c_, f_ = l.slf_attn, l.enc_attn, l.pos_ffn

@@ -153,10 +153,21 @@ def _launch_cast2d(tab):
     L.cast2d_multi(tab[0], tab[1], tab[2], tab[3], tab[4])
 
 
+_weights_epoch = 0
+
+
+def weights_epoch():
+    """Counts the optimiser updates of this process (refresh_derived calls).  Together with the parameters' own version
+    counters — which every other way of changing a parameter advances — it tells a holder of weights in some prepared
+    form (the beam decoder's fragment-major matrices) whether they are still current."""
+    return _weights_epoch
+
+
 def refresh_derived():
     """Rewrite every derived copy from the master parameters (called by the optimiser after its
     update, whose kernel changes the parameters without touching torch's version counters)."""
-    global _derived_tables
+    global _derived_tables, _weights_epoch
+    _weights_epoch += 1
     if not _derived:
         return
     if _derived_tables is None:

@@ -143,3 +143,44 @@ def test_stack_long_histories_match_op_by_op():
         worst = max(worst, err)
         assert err <= 2e-2, (step, err)
     print(f"worst relative difference over {len(ref.trace)} steps: {worst:.4f}")
+
+
+def test_kept_weights_follow_parameter_updates():
+    """A decoder object keeps its prepared weights (stacked q | k | v, fragment-major matrices) between calls: the
+    second call on unchanged weights gives the first call's bits, and after the weights change — through torch (version
+    counters move) or through this package's optimiser (its kernel moves no version counter; ops.weights_epoch
+    does) — a call gives the bits of a fresh decoder object."""
+    from specialk_amd import ops
+    from specialk_amd.decode import BeamDecoder
+    from specialk_amd.optim import FusedAdam
+    m = build(2)
+    src, pos = batch(6, 3, 17, 1000, 11)
+
+    def first_output(dec):
+        dec.trace = []
+        dec.run(src, pos, 1)
+        assert dec.used_stack
+        return dec.trace[0][0].clone()
+
+    dec = BeamDecoder(m, 5, 6, use_graph=False, use_stack=True)
+    x0 = first_output(dec)
+    held = dec._prep[1]
+    assert torch.equal(first_output(dec), x0) and dec._prep[1] is held   # kept, and the same bits
+    with torch.no_grad():
+        for p in m.decoder.parameters():
+            if p.dim() > 1:
+                p.mul_(1.05)
+    ops.refresh_derived()   # the bf16 working copies follow the parameters
+    x1 = first_output(dec)
+    assert dec._prep[1] is not held and not torch.equal(x1, x0)
+    assert torch.equal(x1, first_output(BeamDecoder(m, 5, 6, use_graph=False, use_stack=True)))
+    opt = FusedAdam([p for p in m.parameters()], lr=0.05)
+    for p in m.parameters():
+        p.grad = torch.ones_like(p)
+    versions = [p._version for p in m.decoder.parameters()]
+    opt.step()
+    assert versions == [p._version for p in m.decoder.parameters()]   # the case the update counter exists for
+    x2 = first_output(dec)
+    assert not torch.equal(x2, x1)
+    assert torch.equal(x2, first_output(BeamDecoder(m, 5, 6, use_graph=False, use_stack=True)))
+
