@@ -43,8 +43,8 @@ class BeamDecoder:
     _capture_streams = {}
 
     @classmethod
-    def _capture_pair(cls, step, cur, dev):
-        """Capture two consecutive steps (history table cur -> cur ^ 1 -> cur) into a graph.  The stream of the
+    def _capture_pair(cls, step, cur, dev, pairs=1):
+        """Capture `pairs` pairs of consecutive steps (history table cur -> cur ^ 1 -> cur) into a graph.  The stream of the
         capture is kept per device and gets its kernel workspace before the capture starts, so that no
         allocation that outlives the graph comes from the graph's private pool."""
         stream = cls._capture_streams.get(dev)
@@ -56,8 +56,9 @@ class BeamDecoder:
         torch.cuda.current_stream(dev).wait_stream(stream)
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph, stream=stream):
-            step(False, cur)
-            step(False, cur ^ 1)
+            for _ in range(pairs):
+                step(False, cur)
+                step(False, cur ^ 1)
         return graph
 
     def _prepared(self, layers, dtype, dev):
@@ -272,21 +273,28 @@ class BeamDecoder:
         step(True, 0)  # step 1 expands beam 0 only (Beam.py:51-54)
         steps, cur = 1, 1
         graph = None
+        # Graphs of four steps (two for very short runs): the host looks at the finished-sentence count every fourth step
+        # only — a step past the end changes nothing (finished sentences keep their state) and costs less than a
+        # pipeline drain per step (a blocking read leaves the step stream idle for some 40 us; with steps of 0.5 ms
+        # and runs of 40 .. 150 steps, four is about where drains and steps past the end cost the same).
+        per = 4 if Tmax >= 6 else 2
         if self.use_graph and Tmax >= 3:
-            graph = self._capture_pair(step, cur, dev)
+            graph = self._capture_pair(step, cur, dev, per // 2)
         mark("first step + graph capture")
-        # the host looks at the finished-sentence count every fourth step only: a step past the end changes nothing
-        # (finished sentences keep their state) and costs less than a pipeline drain per step
+        next_look = steps + 4
         while steps < Tmax:
-            if graph is not None and steps + 2 <= Tmax:
+            if graph is not None and steps + per <= Tmax:
                 graph.replay()
-                steps += 2
+                steps += per
             else:
                 step(False, cur)
                 cur ^= 1
                 steps += 1
-            if (steps % 4 <= 1 or steps == Tmax) and int(n_done.item()) == n:
-                break
+            if steps >= next_look or steps == Tmax:
+                finished = int(n_done.item())
+                if finished == n:
+                    break
+                next_look = steps + 4
         mark("steps")
         del graph
         self.last_steps = steps
