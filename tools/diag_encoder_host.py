@@ -20,4 +20,4 @@ with torch.no_grad():
     torch.cuda.synchronize()
     pr.disable()
 st = pstats.Stats(pr)
-st.sort_stats("cumulative").print_stats(28)
+st.sort_stats("tottime").print_stats(22)
