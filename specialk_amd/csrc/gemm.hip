@@ -238,7 +238,8 @@ __device__ __forceinline__ void write_tile(const GemmParams& p, const f32x4_t (*
       // instruction of 16 bytes per lane leaves four 16-byte pieces 64 bytes apart in every row and a 128-byte line
       // is put together from eight separate writes in the L2 — the stores were 30 of the product's 70 us.  A 4 x 4
       // transpose of the 16-byte pieces across those lanes first (two exchange rounds) makes every instruction
-      // write 64 consecutive bytes per row.
+      // write 64 consecutive bytes per row.  (Going on to whole 128-byte lines — neighbouring rows trading half of
+      // their pieces, eight lanes per line — measured the same 56-57 us.)
       bool stored = false;
       if constexpr (sizeof(TOut) == 4) {
         if ((p.epi & SK_EPI_ROWSTATS) && slab < 0 && p.vec_c && col0 + 64 <= p.N) {
