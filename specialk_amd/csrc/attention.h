@@ -21,6 +21,7 @@ struct AttnParams {
   uint32_t drop_thr;
   float keep_scale;
   uint64_t seed;
+  int wide_store;   // output rows stored as 16-byte pieces, 64 consecutive bytes per row and instruction (MFMA kernels)
 };
 
 template <typename T>

@@ -306,6 +306,7 @@ int attn_fwd_impl(const void* Q, const void* K, const void* V, void* O, float* L
   p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo;
   p.scale = scale; p.causal = causal;
   p.drop_thr = sk_drop_threshold(p_drop); p.keep_scale = 1.0f / (1.0f - p_drop); p.seed = seed;
+  { const char* e = getenv("SKHIP_ATTN_WIDE"); p.wide_store = !(e && e[0] == '0'); }
   if (Lk > 0 && !force_valu() && sk_attn_mfma_supported(p, dtype, P_out != nullptr)) return sk_attn_fwd_mfma(p, stream);
   dim3 grid((Lq + OWN - 1) / OWN, n_head, B);
   size_t smem = sizeof(float) * ((size_t)TILE * (dk + 1) + (size_t)TILE * (dv + 1) + (size_t)OWN * (dk + 1));
@@ -338,6 +339,7 @@ int attn_bwd_impl(const void* Q, const void* K, const void* V, const void* O, co
   p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo; p.lddq = lddq; p.lddk = lddk; p.lddv = lddv;
   p.scale = scale; p.causal = causal;
   p.drop_thr = sk_drop_threshold(p_drop); p.keep_scale = 1.0f / (1.0f - p_drop); p.seed = seed;
+  { const char* e = getenv("SKHIP_ATTN_WIDE"); p.wide_store = !(e && e[0] == '0'); }
   if (!force_valu() && sk_attn_mfma_supported(p, dtype, false)) return sk_attn_bwd_mfma(p, stream);
   int64_t rows = (int64_t)B * n_head * Lq;
   unsigned dblocks = (unsigned)((rows + 3) / 4 < 4096 ? (rows + 3) / 4 : 4096);

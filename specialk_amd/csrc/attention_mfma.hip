@@ -85,6 +85,44 @@ __device__ __forceinline__ float quad_sum(float v) {
 }
 
 // ------------------------------------------------------------------------------ forward
+// A row of D output columns leaves the multiplications as w[t] = the four bf16 of columns 16 t + 4 g .. of lane
+// (row, g): stored as they are, an instruction writes four 8-byte pieces per row and a 128-byte line comes together
+// from sixteen writes in the L2.  Two exchange rounds among the row's four lanes per 32 columns — piece index against
+// lane bit 0, then the two lane bits against each other — leave lane g with columns 32 u + 8 g .. + 7, and an
+// instruction writes 64 consecutive bytes per row.  All four lanes of a row call this together.
+template <int D>
+__device__ __forceinline__ void store_row_wide(bf16_t* out, const uint2 (&w)[D / 16], int lane) {
+  const int g = lane >> 4;
+  const bool b = g & 1;
+  const int src = (lane & 15) + 16 * (((g & 1) << 1) | (g >> 1));
+#pragma unroll
+  for (int u = 0; u < D / 32; ++u) {
+    const uint2 p0 = w[2 * u], p1 = w[2 * u + 1];
+    const uint2 send = b ? p0 : p1;
+    uint2 recv;
+    recv.x = __shfl_xor(send.x, 16, 64);
+    recv.y = __shfl_xor(send.y, 16, 64);
+    const uint2 r0 = b ? recv : p0, r1 = b ? p1 : recv;
+    uint4 q;
+    q.x = __shfl(r0.x, src, 64);
+    q.y = __shfl(r0.y, src, 64);
+    q.z = __shfl(r1.x, src, 64);
+    q.w = __shfl(r1.y, src, 64);
+    if (out) *(uint4*)(out + 32 * u + 8 * g) = q;
+  }
+}
+
+template <int D>
+__device__ __forceinline__ void store_row(bf16_t* out, bool row_ok, bool wide, const uint2 (&w)[D / 16], int lane) {
+  if (wide) {   // kernel-uniform
+    store_row_wide<D>(row_ok ? out : nullptr, w, lane);
+  } else if (row_ok) {
+    const int g = lane >> 4;
+#pragma unroll
+    for (int t = 0; t < D / 16; ++t) *(uint2*)(out + 16 * t + 4 * g) = w[t];
+  }
+}
+
 template <int D>
 __global__ __launch_bounds__(256, (D <= 64 ? 6 : 4)) void attn_fwd_mfma_kernel(AttnParams p) {
   __shared__ __attribute__((aligned(16))) Tile<D> Ks;
@@ -169,18 +207,17 @@ __global__ __launch_bounds__(256, (D <= 64 ? 6 : 4)) void attn_fwd_mfma_kernel(A
         o[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x_cols<D>(Vs, 16 * t, 1, lane), y1, o[t], 0, 0, 0);
     }
   }
-  if (q < Lq) {
+  {
     const float inv = 1.0f / l;  // fully masked row: 0 * inf = NaN, like the reference's softmax
-    bf16_t* O = (bf16_t*)p.Oout + (sq.qbase + q) * p.ldo + h * D;
+    uint2 w[D / 16];
 #pragma unroll
     for (int t = 0; t < D / 16; ++t) {
-      uint2 w;
-      bf16_t* e = (bf16_t*)&w;
+      bf16_t* e = (bf16_t*)&w[t];
 #pragma unroll
       for (int r = 0; r < 4; ++r) e[r] = f32_to_bf16(o[t][r] * inv);
-      *(uint2*)(O + 16 * t + 4 * g) = w;
     }
-    if (g == 0) p.LSE[((int64_t)b * p.H + h) * p.Lq + q] = m + __logf(l);
+    store_row<D>((bf16_t*)p.Oout + (sq.qbase + min(q, Lq - 1)) * p.ldo + h * D, q < Lq, p.wide_store != 0, w, lane);
+    if (q < Lq && g == 0) p.LSE[((int64_t)b * p.H + h) * p.Lq + q] = m + __logf(l);
   }
 }
 
@@ -259,16 +296,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(AttnParams p) {
       dq[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x_cols<D>(Ks, 16 * t, 1, lane), y1, dq[t], 0, 0, 0);
     }
   }
-  if (q < Lq) {
-    bf16_t* out = (bf16_t*)p.dQ + (sq.qbase + q) * p.lddq + h * D;
+  {
+    uint2 w[D / 16];
 #pragma unroll
     for (int t = 0; t < D / 16; ++t) {
-      uint2 w;
-      bf16_t* e = (bf16_t*)&w;
+      bf16_t* e = (bf16_t*)&w[t];
 #pragma unroll
       for (int r = 0; r < 4; ++r) e[r] = f32_to_bf16(dq[t][r]);
-      *(uint2*)(out + 16 * t + 4 * g) = w;
     }
+    store_row<D>((bf16_t*)p.dQ + (sq.qbase + min(q, Lq - 1)) * p.lddq + h * D, q < Lq, p.wide_store && !(p.lddq & 7), w, lane);
   }
 }
 
@@ -347,19 +383,18 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(AttnParams p) {
       dk[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x_cols<D>(Qs, 16 * t, 1, lane), ys1, dk[t], 0, 0, 0);
     }
   }
-  if (j < Lk) {
-    bf16_t* oK = (bf16_t*)p.dK + (sq.kbase + j) * p.lddk + h * D;
-    bf16_t* oV = (bf16_t*)p.dV + (sq.kbase + j) * p.lddv + h * D;
+  {
+    uint2 wk[D / 16], wv[D / 16];
 #pragma unroll
     for (int t = 0; t < D / 16; ++t) {
-      uint2 wk, wv;
-      bf16_t* ek = (bf16_t*)&wk;
-      bf16_t* ev = (bf16_t*)&wv;
+      bf16_t* ek = (bf16_t*)&wk[t];
+      bf16_t* ev = (bf16_t*)&wv[t];
 #pragma unroll
       for (int r = 0; r < 4; ++r) { ek[r] = f32_to_bf16(dk[t][r]); ev[r] = f32_to_bf16(dv[t][r]); }
-      *(uint2*)(oK + 16 * t + 4 * g) = wk;
-      *(uint2*)(oV + 16 * t + 4 * g) = wv;
     }
+    const bool wide = p.wide_store && !((p.lddk | p.lddv) & 7);
+    store_row<D>((bf16_t*)p.dK + (sq.kbase + min(j, Lk - 1)) * p.lddk + h * D, j < Lk, wide, wk, lane);
+    store_row<D>((bf16_t*)p.dV + (sq.kbase + min(j, Lk - 1)) * p.lddv + h * D, j < Lk, wide, wv, lane);
   }
 }
 
@@ -477,16 +512,15 @@ __global__ __launch_bounds__(256) void attn_bwd_fused_mfma_kernel(AttnParams p) 
         if (two_k_halves)
           dq[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x_cols<D>(Ks, 16 * t, 1, lane), y1, dq[t], 0, 0, 0);
       }
-      if (q < Lq) {  // the multiplications above ran with every lane; only the stores are guarded
-        bf16_t* out = (bf16_t*)p.dQ + (sq.qbase + q) * p.lddq + h * D;
+      {  // the multiplications above ran with every lane; only the stores are guarded
+        uint2 w[D / 16];
 #pragma unroll
         for (int t = 0; t < D / 16; ++t) {
-          uint2 w;
-          bf16_t* e = (bf16_t*)&w;
+          bf16_t* e = (bf16_t*)&w[t];
 #pragma unroll
           for (int r = 0; r < 4; ++r) e[r] = f32_to_bf16(dq[t][r]);
-          *(uint2*)(out + 16 * t + 4 * g) = w;
         }
+        store_row<D>((bf16_t*)p.dQ + (sq.qbase + min(q, Lq - 1)) * p.lddq + h * D, q < Lq, p.wide_store && !(p.lddq & 7), w, lane);
       }
     }
     // P (with the dropout scaling) and dS of the own query row replace the K and V tiles, which
@@ -526,19 +560,18 @@ __global__ __launch_bounds__(256) void attn_bwd_fused_mfma_kernel(AttnParams p) 
         dk[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x_cols<D>(Qs, 16 * t, 1, lane), ys1, dk[t], 0, 0, 0);
       }
     }
-    if (j < Lk) {
-      bf16_t* oK = (bf16_t*)p.dK + (sq.kbase + j) * p.lddk + h * D;
-      bf16_t* oV = (bf16_t*)p.dV + (sq.kbase + j) * p.lddv + h * D;
+    {
+      uint2 wk[D / 16], wv[D / 16];
 #pragma unroll
       for (int t = 0; t < D / 16; ++t) {
-        uint2 wk, wv;
-        bf16_t* ek = (bf16_t*)&wk;
-        bf16_t* ev = (bf16_t*)&wv;
+        bf16_t* ek = (bf16_t*)&wk[t];
+        bf16_t* ev = (bf16_t*)&wv[t];
 #pragma unroll
         for (int r = 0; r < 4; ++r) { ek[r] = f32_to_bf16(dk[t][r]); ev[r] = f32_to_bf16(dv[t][r]); }
-        *(uint2*)(oK + 16 * t + 4 * g) = wk;
-        *(uint2*)(oV + 16 * t + 4 * g) = wv;
       }
+      const bool wide = p.wide_store && !((p.lddk | p.lddv) & 7);
+      store_row<D>((bf16_t*)p.dK + (sq.kbase + min(j, Lk - 1)) * p.lddk + h * D, j < Lk, wide, wk, lane);
+      store_row<D>((bf16_t*)p.dV + (sq.kbase + min(j, Lk - 1)) * p.lddv + h * D, j < Lk, wide, wv, lane);
     }
   }
 }
