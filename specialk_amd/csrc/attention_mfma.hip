@@ -90,14 +90,15 @@ __device__ __forceinline__ float quad_sum(float v) {
 // from sixteen writes in the L2.  Two exchange rounds among the row's four lanes per 32 columns — piece index against
 // lane bit 0, then the two lane bits against each other — leave lane g with columns 32 u + 8 g .. + 7, and an
 // instruction writes 64 consecutive bytes per row.  All four lanes of a row call this together.
-template <int D>
-__device__ __forceinline__ void store_row_wide(bf16_t* out, const uint2 (&w)[D / 16], int lane) {
+// piece(t): the row's w[t], made on demand (the fp32 values it comes from die as the loop goes).
+template <int D, class F>
+__device__ __forceinline__ void store_row_wide(bf16_t* out, F&& piece, int lane) {
   const int g = lane >> 4;
   const bool b = g & 1;
   const int src = (lane & 15) + 16 * (((g & 1) << 1) | (g >> 1));
 #pragma unroll
   for (int u = 0; u < D / 32; ++u) {
-    const uint2 p0 = w[2 * u], p1 = w[2 * u + 1];
+    const uint2 p0 = piece(2 * u), p1 = piece(2 * u + 1);
     const uint2 send = b ? p0 : p1;
     uint2 recv;
     recv.x = __shfl_xor(send.x, 16, 64);
@@ -112,15 +113,23 @@ __device__ __forceinline__ void store_row_wide(bf16_t* out, const uint2 (&w)[D /
   }
 }
 
-template <int D>
-__device__ __forceinline__ void store_row(bf16_t* out, bool row_ok, bool wide, const uint2 (&w)[D / 16], int lane) {
+template <int D, class F>
+__device__ __forceinline__ void store_row(bf16_t* out, bool row_ok, bool wide, F&& piece, int lane) {
   if (wide) {   // kernel-uniform
-    store_row_wide<D>(row_ok ? out : nullptr, w, lane);
+    store_row_wide<D>(row_ok ? out : nullptr, piece, lane);
   } else if (row_ok) {
     const int g = lane >> 4;
 #pragma unroll
-    for (int t = 0; t < D / 16; ++t) *(uint2*)(out + 16 * t + 4 * g) = w[t];
+    for (int t = 0; t < D / 16; ++t) *(uint2*)(out + 16 * t + 4 * g) = piece(t);
   }
+}
+
+__device__ __forceinline__ uint2 pack4_bf16(const f32x4_t v, float scale) {
+  uint2 w;
+  bf16_t* e = (bf16_t*)&w;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) e[r] = f32_to_bf16(v[r] * scale);
+  return w;
 }
 
 template <int D>
@@ -207,17 +216,20 @@ __global__ __launch_bounds__(256, (D <= 64 ? 6 : 4)) void attn_fwd_mfma_kernel(A
         o[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x_cols<D>(Vs, 16 * t, 1, lane), y1, o[t], 0, 0, 0);
     }
   }
-  {
+  if (q < Lq) {
+    // (8-byte pieces here: this kernel runs six waves to a SIMD on 80 registers, and the exchange of the wide form
+    // put four of them into scratch memory — 33 -> 36 us per launch)
     const float inv = 1.0f / l;  // fully masked row: 0 * inf = NaN, like the reference's softmax
-    uint2 w[D / 16];
+    bf16_t* O = (bf16_t*)p.Oout + (sq.qbase + q) * p.ldo + h * D;
 #pragma unroll
     for (int t = 0; t < D / 16; ++t) {
-      bf16_t* e = (bf16_t*)&w[t];
+      uint2 w;
+      bf16_t* e = (bf16_t*)&w;
 #pragma unroll
       for (int r = 0; r < 4; ++r) e[r] = f32_to_bf16(o[t][r] * inv);
+      *(uint2*)(O + 16 * t + 4 * g) = w;
     }
-    store_row<D>((bf16_t*)p.Oout + (sq.qbase + min(q, Lq - 1)) * p.ldo + h * D, q < Lq, p.wide_store != 0, w, lane);
-    if (q < Lq && g == 0) p.LSE[((int64_t)b * p.H + h) * p.Lq + q] = m + __logf(l);
+    if (g == 0) p.LSE[((int64_t)b * p.H + h) * p.Lq + q] = m + __logf(l);
   }
 }
 
@@ -297,14 +309,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(AttnParams p) {
     }
   }
   {
-    uint2 w[D / 16];
-#pragma unroll
-    for (int t = 0; t < D / 16; ++t) {
-      bf16_t* e = (bf16_t*)&w[t];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) e[r] = f32_to_bf16(dq[t][r]);
-    }
-    store_row<D>((bf16_t*)p.dQ + (sq.qbase + min(q, Lq - 1)) * p.lddq + h * D, q < Lq, p.wide_store && !(p.lddq & 7), w, lane);
+    store_row<D>((bf16_t*)p.dQ + (sq.qbase + min(q, Lq - 1)) * p.lddq + h * D, q < Lq, p.wide_store && !(p.lddq & 7),
+                 [&](int t) { return pack4_bf16(dq[t], 1.0f); }, lane);
   }
 }
 
@@ -384,17 +390,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(AttnParams p) {
     }
   }
   {
-    uint2 wk[D / 16], wv[D / 16];
-#pragma unroll
-    for (int t = 0; t < D / 16; ++t) {
-      bf16_t* ek = (bf16_t*)&wk[t];
-      bf16_t* ev = (bf16_t*)&wv[t];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) { ek[r] = f32_to_bf16(dk[t][r]); ev[r] = f32_to_bf16(dv[t][r]); }
-    }
     const bool wide = p.wide_store && !((p.lddk | p.lddv) & 7);
-    store_row<D>((bf16_t*)p.dK + (sq.kbase + min(j, Lk - 1)) * p.lddk + h * D, j < Lk, wide, wk, lane);
-    store_row<D>((bf16_t*)p.dV + (sq.kbase + min(j, Lk - 1)) * p.lddv + h * D, j < Lk, wide, wv, lane);
+    store_row<D>((bf16_t*)p.dK + (sq.kbase + min(j, Lk - 1)) * p.lddk + h * D, j < Lk, wide,
+                 [&](int t) { return pack4_bf16(dk[t], 1.0f); }, lane);
+    store_row<D>((bf16_t*)p.dV + (sq.kbase + min(j, Lk - 1)) * p.lddv + h * D, j < Lk, wide,
+                 [&](int t) { return pack4_bf16(dv[t], 1.0f); }, lane);
   }
 }
 
@@ -513,14 +513,8 @@ __global__ __launch_bounds__(256) void attn_bwd_fused_mfma_kernel(AttnParams p) 
           dq[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x_cols<D>(Ks, 16 * t, 1, lane), y1, dq[t], 0, 0, 0);
       }
       {  // the multiplications above ran with every lane; only the stores are guarded
-        uint2 w[D / 16];
-#pragma unroll
-        for (int t = 0; t < D / 16; ++t) {
-          bf16_t* e = (bf16_t*)&w[t];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) e[r] = f32_to_bf16(dq[t][r]);
-        }
-        store_row<D>((bf16_t*)p.dQ + (sq.qbase + min(q, Lq - 1)) * p.lddq + h * D, q < Lq, p.wide_store && !(p.lddq & 7), w, lane);
+        store_row<D>((bf16_t*)p.dQ + (sq.qbase + min(q, Lq - 1)) * p.lddq + h * D, q < Lq, p.wide_store && !(p.lddq & 7),
+                     [&](int t) { return pack4_bf16(dq[t], 1.0f); }, lane);
       }
     }
     // P (with the dropout scaling) and dS of the own query row replace the K and V tiles, which
@@ -561,17 +555,11 @@ __global__ __launch_bounds__(256) void attn_bwd_fused_mfma_kernel(AttnParams p) 
       }
     }
     {
-      uint2 wk[D / 16], wv[D / 16];
-#pragma unroll
-      for (int t = 0; t < D / 16; ++t) {
-        bf16_t* ek = (bf16_t*)&wk[t];
-        bf16_t* ev = (bf16_t*)&wv[t];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { ek[r] = f32_to_bf16(dk[t][r]); ev[r] = f32_to_bf16(dv[t][r]); }
-      }
       const bool wide = p.wide_store && !((p.lddk | p.lddv) & 7);
-      store_row<D>((bf16_t*)p.dK + (sq.kbase + min(j, Lk - 1)) * p.lddk + h * D, j < Lk, wide, wk, lane);
-      store_row<D>((bf16_t*)p.dV + (sq.kbase + min(j, Lk - 1)) * p.lddv + h * D, j < Lk, wide, wv, lane);
+      store_row<D>((bf16_t*)p.dK + (sq.kbase + min(j, Lk - 1)) * p.lddk + h * D, j < Lk, wide,
+                   [&](int t) { return pack4_bf16(dk[t], 1.0f); }, lane);
+      store_row<D>((bf16_t*)p.dV + (sq.kbase + min(j, Lk - 1)) * p.lddv + h * D, j < Lk, wide,
+                   [&](int t) { return pack4_bf16(dv[t], 1.0f); }, lane);
     }
   }
 }
