@@ -233,7 +233,7 @@ __device__ __forceinline__ void write_tile(const GemmParams& p, const f32x4_t (*
       for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[ni * 4 + r] = acc[mi][ni][r];
-      // fp32 rows of a plain product with statistics (the decode step's 90 MB of log-probabilities): the four lanes
+      // fp32 rows of a plain product, with or without statistics (the decode step's 90 MB of log-probabilities): the four lanes
       // l, l + 16, l + 32, l + 48 hold 64 consecutive columns of one row, each lane 16 of them, so a store
       // instruction of 16 bytes per lane leaves four 16-byte pieces 64 bytes apart in every row and a 128-byte line
       // is put together from eight separate writes in the L2 — the stores were 30 of the product's 70 us.  A 4 x 4
@@ -242,7 +242,7 @@ __device__ __forceinline__ void write_tile(const GemmParams& p, const f32x4_t (*
       // their pieces, eight lanes per line — measured the same 56-57 us.)
       bool stored = false;
       if constexpr (sizeof(TOut) == 4) {
-        if ((p.epi & SK_EPI_ROWSTATS) && slab < 0 && p.vec_c && col0 + 64 <= p.N) {
+        if ((p.epi & ~SK_EPI_ROWSTATS) == 0 && p.alpha == 1.0f && slab < 0 && p.vec_c && col0 + 64 <= p.N) {
           float t[16];
 #pragma unroll
           for (int j = 0; j < 16; ++j) t[j] = v[j];
