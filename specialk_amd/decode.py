@@ -66,10 +66,14 @@ class BeamDecoder:
         current as long as no optimiser update of this package has run (ops.weights_epoch: its kernel changes parameters
         without touching torch's version counters) and no parameter's version counter has moved (every other way of
         writing a parameter).  SK_DECODE_KEEP_WEIGHTS=0: rebuilt every call."""
-        key = (ops.weights_epoch(), dtype, dev, tuple((id(p), p._version) for l in layers for p in l.parameters()))
+        params = [p for l in layers for p in l.parameters()]
+        key = (ops.weights_epoch(), dtype, dev, tuple(p._version for p in params))
         held = getattr(self, "_prep", None)
-        if held is None or held[0] != key or os.environ.get("SK_DECODE_KEEP_WEIGHTS", "1") == "0":
-            held = self._prep = (key, {})
+        # (the parameters themselves are held with the key and compared by identity: an id alone could be a new
+        # tensor's at a freed one's address)
+        if (held is None or held[0] != key or len(held[2]) != len(params) or any(a is not b for a, b in zip(held[2], params))
+                or os.environ.get("SK_DECODE_KEEP_WEIGHTS", "1") == "0"):
+            held = self._prep = (key, {}, params)
         return held[1]
 
     def _w(self, p, dtype):
