@@ -70,7 +70,8 @@ def build(cfg, dtype, device):
         if p.dim() > 1:
             torch.nn.init.xavier_uniform_(p)
     m = m.to(device).set_compute_dtype(dtype)
-    m.encoder.check_ids = m.decoder.check_ids = False  # synthetic ids are valid by construction
+    if os.environ.get("SK_BENCH_CHECK_IDS", "1") == "0":  # (the trainer keeps the id / position range check: so does the bench)
+        m.encoder.check_ids = m.decoder.check_ids = False
     m.train()
     opt = ScheduledOptim(FusedAdam(filter(lambda x: x.requires_grad, m.parameters()), betas=(0.9, 0.98), eps=1e-09),
                          cfg["d_model"], 4000)
@@ -331,6 +332,34 @@ def decode_step_bytes(m, n, bm, Ls, steps):
     return steps * per_step_fixed + hist
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher around it: start N ranks (one per GPU) as children of
+    torch.distributed.run with this script's own arguments, relay rank 0's result line and return the exit code to
+    use.  The launcher process makes no GPU call (importing torch does not initialise the device)."""
+    import socket
+    import subprocess
+    if torch.cuda.device_count() < n and "SK_BENCH_DEVICE" not in os.environ:
+        print(f"bench.py: --gpus {n} but {torch.cuda.device_count()} visible", file=sys.stderr)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
+    if proc.returncode != 0 or not lines:
+        print(f"bench.py: the {n}-rank run failed (exit {proc.returncode}, {len(lines)} result lines)", file=sys.stderr)
+        return proc.returncode or 1
+    out = json.loads(lines[-1])
+    if out.get("n_gpus") != n or out.get("ranks_seen") != n:
+        print(f"bench.py: asked for {n} ranks, the result reports n_gpus={out.get('n_gpus')} "
+              f"ranks_seen={out.get('ranks_seen')}", file=sys.stderr)
+        return 1
+    print(lines[-1], flush=True)
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -346,6 +375,12 @@ def main():
                     help="profiling aid: run only the beam-decode leg (worst case, 3 batches) and print its result")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started as a plain `python bench.py --gpus N`: this process becomes the launcher (it never touches a
+        # GPU) and the N ranks are fresh children of torch.distributed.run, as lib/train.py:385-388's fan-out over
+        # the visible devices would be; rank 0's one result line is relayed, any failing rank fails the run
+        raise SystemExit(launch_ranks(args.gpus))
+
     # stdout carries exactly one line, the result: libraries that write to file descriptor 1 themselves (RCCL
     # prints a version banner at start-up) are pointed at stderr for the whole run
     sys.stdout.flush()
@@ -355,7 +390,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("SK_BENCH_DEVICE", os.environ.get("LOCAL_RANK", "0")))  # override: rehearsals on one card
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
@@ -417,8 +452,16 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
 
+    ranks_seen, rank_ms = 1, [round(elapsed / args.steps * 1e3, 3)]
     if dist_on:
         red_dev = device if dist.get_backend() == "nccl" else "cpu"
+        ones = torch.ones(1, dtype=torch.float64, device=red_dev)  # how many ranks took part, counted by the collective itself
+        dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+        ranks_seen = int(ones.item())
+        per_rank = torch.zeros(world, dtype=torch.float64, device=red_dev)
+        per_rank[rank] = elapsed / args.steps * 1e3
+        dist.all_reduce(per_rank, op=dist.ReduceOp.SUM)
+        rank_ms = [round(v, 3) for v in per_rank.tolist()]
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -430,7 +473,7 @@ def main():
     if rank == 0:
         out = {
             "metric": "train target tokens/sec", "value": round(tokens / elapsed, 1), "unit": "tokens/sec",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": world, "ranks_seen": ranks_seen, "ms_per_step_by_rank": rank_ms, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": cfg["desc"], "config_name": args.config, "per_gpu_sentences": cfg["batch"],

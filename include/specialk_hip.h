@@ -191,6 +191,45 @@ int skhip_add_ln_bwd(const void* dy, const void* x, const void* res, const float
                      float* partial_ws, int64_t T, int d, float p_drop, uint64_t seed, int accumulate,
                      int dtype, void* stream);
 
+/* ---- row-panel products (d_model = 512, bf16) -----------------------------------------------
+ * The activation-sized products of the layers with the token ROWS as the unit of work: a workgroup keeps
+ * SK_ROWPANEL_ROWS rows in LDS, every wave owns 64 of 512 output columns and streams its slice of the weights
+ * (stored FRAGMENT-MAJOR by skhip_cast2d_multi, meta flag bits 2-3 = 2) from the L2 straight into the MFMA operand
+ * registers.  25.6 k rows are 247 workgroups: one round of the chip.  Results equal skhip_gemm's (+ skhip_add_ln_fwd's)
+ * up to fp32 summation order.  All operands 16-byte aligned, row strides multiples of 8 elements; any T (the callers
+ * use these entry points when T / SK_ROWPANEL_ROWS fills the chip, see ops.py).
+ *
+ * skhip_rowpanel_gemm: c [T][N] = epilogue(a [T][512] w^T), w [N][512] fragment-major, N a multiple of 512 — nn.Linear /
+ * Conv1d(k=1) forward and input gradient with a 512-deep contraction (SubLayers.py:46-48,62,73,80 and their autograd
+ * backward).  epilogue: 0, SK_EPI_BIAS, SK_EPI_BIAS | SK_EPI_RELU | SK_EPI_RELU_BITS_OUT (signs receives the pattern,
+ * skhip_gemm's format), SK_EPI_RELU_MASK_BITS (signs is read), SK_EPI_ACCUM (c += ...).
+ * skhip_rowpanel_gemm_ln: N = 512 and the sub-layer tail as the epilogue — replaces `self.layer_norm(self.dropout(
+ * self.fc(output)) + residual)` (SubLayers.py:62-63) = skhip_gemm + skhip_add_ln_fwd:  sub_out = a w^T + bias [T][512]
+ * (stored: the backward pass reads it), y = LayerNorm(res + dropout_p(sub_out)) gamma + beta with pad rows zeroed,
+ * mean / rstd [T] as skhip_add_ln_fwd leaves them.
+ * skhip_rowstream_gemm / _ln: the same two forms for N = 512 and a contraction K that is a multiple of 256 (w [512][K]
+ * fragment-major), the rows' K extent streamed through LDS: the feed-forward w_2 with its LayerNorm (SubLayers.py:81-84),
+ * its input gradient accumulated into the residual-branch gradient (accumulate != 0: c += a w^T), the input gradient of
+ * the stacked q | k | v projections.                                                                          */
+#define SK_ROWPANEL_ROWS 104
+int skhip_rowpanel_rows(void);
+/* Diagnostics (no counterpart in the reference): with a device buffer of ceil(T / SK_ROWPANEL_ROWS) * 8 * 32 uint64 set,
+ * every wave of the row-panel kernels leaves shader-clock readings at its phase boundaries there; NULL (the start
+ * value) turns it off.  Process-wide, not thread-safe.                                                         */
+int skhip_rowpanel_set_stamps(void* buffer);
+int skhip_rowpanel_gemm(const void* a, int64_t lda, const void* w_fm, const float* bias, void* c, int64_t ldc,
+                        void* signs, int64_t T, int64_t N, int epilogue, void* stream);
+int skhip_rowpanel_gemm_ln(const void* a, int64_t lda, const void* w_fm, const float* bias, const void* res,
+                           int64_t ldres, void* sub_out, const float* gamma, const float* beta,
+                           const uint8_t* row_pad, void* y, float* mean, float* rstd, int64_t T, float eps,
+                           float p_drop, uint64_t seed, void* stream);
+int skhip_rowstream_gemm(const void* a, int64_t lda, int64_t K, const void* w_fm, const float* bias, void* c,
+                         int64_t ldc, int accumulate, int64_t T, void* stream);
+int skhip_rowstream_gemm_ln(const void* a, int64_t lda, int64_t K, const void* w_fm, const float* bias,
+                            const void* res, int64_t ldres, void* sub_out, const float* gamma, const float* beta,
+                            const uint8_t* row_pad, void* y, float* mean, float* rstd, int64_t T, float eps,
+                            float p_drop, uint64_t seed, void* stream);
+
 /* ---- embeddings ----------------------------------------------------------------------
  * out[t] = word_emb[seq[t]] + pos_table[pos[t]]   (lib/transformer/Models.py:117-118,
  * 181-182; no sqrt(d) scaling).  Tables are fp32 (master weights); out is `dtype`.        */
@@ -288,7 +327,12 @@ int skhip_cast_multi(const uint64_t* src_f32_ptrs, const uint64_t* dst_bf16_ptrs
  * entry: R, C, ld, flags (bit 0: transpose, bit 1: fp32 destination).  Used to keep [Wq;Wk;Wv]
  * row-concatenations (one fused projection GEMM instead of SubLayers.py:46-48's three) and W^T
  * copies (input-gradient GEMMs with a K-contiguous weight operand).  max_tiles = the largest
- * ceil(R/32)*ceil(C/32) over the entries.                                                  */
+ * ceil(R/32)*ceil(C/32) over the entries.
+ * flags bits 2-3 = t in {1, 2}: the destination (bf16) is FRAGMENT-MAJOR with T = 2 t tiles per group (the row-panel
+ * kernels above read T = 4): the [N][K] matrix (after the optional transpose; N % (16 T) == 0,
+ * K % 32 == 0) is stored as [N / (16 T)][K' / 32][T][64][8] with K' = ld if ld > 0 (the entry is then a K slice of a
+ * wider destination and dst points at its first K-step), else K, where tile ti of a group holds as its row
+ * i the group's row 4 T (i / 4) + 4 ti + i % 4, and lane i + 16 g of a tile the elements k = 8 g .. 8 g + 7.   */
 int skhip_cast2d_multi(const uint64_t* src_f32_ptrs, const uint64_t* dst_ptrs, const int64_t* meta,
                        int n, int64_t max_tiles, void* stream);
 /* dst[i] = convert(src[i]); dtypes SK_F32 / SK_BF16.                                      */

@@ -25,6 +25,7 @@ EXPORTS = [
     "skhip_decode_attn", "skhip_beam_topk_ws_bytes", "skhip_beam_topk", "skhip_beam_update", "skhip_gather_rows",
     "skhip_decode_stack_ws_bytes", "skhip_decode_stack", "skhip_beam_topk_stats", "skhip_beam_step",
     "skhip_softmax_rows", "skhip_conv_windows", "skhip_cnn_head", "skhip_collate", "skhip_set_reserved_cus",
+    "skhip_rowpanel_rows", "skhip_rowpanel_set_stamps", "skhip_rowpanel_gemm", "skhip_rowpanel_gemm_ln", "skhip_rowstream_gemm", "skhip_rowstream_gemm_ln",
 ]
 
 _lib = None
@@ -80,6 +81,11 @@ def load():
     lib.skhip_decode_stack_ws_bytes.restype = c_i64
     lib.skhip_decode_stack.argtypes = [c_p, c_int] + [c_p] * 11 + [c_i64] + [c_int] * 8 + [c_f32, c_f32, c_int, c_p]
     lib.skhip_gather_rows.argtypes = [c_p] * 3 + [c_i64] * 4 + [c_int, c_p]
+    lib.skhip_rowpanel_set_stamps.argtypes = [c_p]
+    lib.skhip_rowpanel_gemm.argtypes = [c_p, c_i64, c_p, c_p, c_p, c_i64, c_p, c_i64, c_i64, c_int, c_p]
+    lib.skhip_rowpanel_gemm_ln.argtypes = [c_p, c_i64, c_p, c_p, c_p, c_i64] + [c_p] * 7 + [c_i64, c_f32, c_f32, c_u64, c_p]
+    lib.skhip_rowstream_gemm.argtypes = [c_p, c_i64, c_i64, c_p, c_p, c_p, c_i64, c_int, c_i64, c_p]
+    lib.skhip_rowstream_gemm_ln.argtypes = [c_p, c_i64, c_i64, c_p, c_p, c_p, c_i64] + [c_p] * 7 + [c_i64, c_f32, c_f32, c_u64, c_p]
     for name in EXPORTS:
         getattr(lib, name)  # AttributeError here means header and library disagree
     _lib = lib
@@ -210,6 +216,64 @@ def colsum_noalloc(X, M, N, ldx, out, accumulate=False):
     _check(load().skhip_colsum_noalloc(_ptr(X), _ptr(out), M, N, ldx, int(accumulate), dcode(X.dtype), _stream()),
            "skhip_colsum_noalloc")
     return out
+
+
+# --------------------------------------------------------------------------- row-panel products (d_model = 512, bf16)
+ROWPANEL_ROWS = 104
+
+
+def rowpanel_set_stamps(buf):
+    """Diagnostics: int64 device tensor of ceil(T / 104) * 8 * 32 entries that the row-panel kernels fill with clock
+    readings (None: off)."""
+    _check(load().skhip_rowpanel_set_stamps(_ptr(buf)), "skhip_rowpanel_set_stamps")
+
+
+def rowpanel_gemm(a, w_fm, N, bias=None, out=None, ldc=None, signs=None, epilogue=0):
+    """out (T, N) = epilogue(a (T, 512; any row stride) w^T) with w (N, 512) fragment-major (ops.derived_weight "fm")."""
+    T = a.shape[0]
+    assert a.dtype == torch.bfloat16 and a.shape[1] == 512 and a.stride(1) == 1
+    if out is None:
+        out, ldc = torch.empty((T, N), dtype=torch.bfloat16, device=a.device), N
+    if bias is not None:
+        epilogue |= EPI_BIAS
+    _check(load().skhip_rowpanel_gemm(_ptr(a), a.stride(0), _ptr(w_fm), _ptr(bias), _ptr(out), ldc, _ptr(signs), T, N,
+                                      epilogue, _stream()), "skhip_rowpanel_gemm")
+    return out
+
+
+def rowstream_gemm(a, w_fm, K, bias=None, out=None, ldc=512, accumulate=False):
+    """out (T, 512) (+)= a (T, K; any row stride) w^T with w (512, K) fragment-major."""
+    T = a.shape[0]
+    assert a.dtype == torch.bfloat16 and a.shape[1] == K and a.stride(1) == 1
+    if out is None:
+        assert not accumulate
+        out = torch.empty((T, 512), dtype=torch.bfloat16, device=a.device)
+    _check(load().skhip_rowstream_gemm(_ptr(a), a.stride(0), K, _ptr(w_fm), _ptr(bias), _ptr(out), ldc, int(accumulate), T,
+                                       _stream()), "skhip_rowstream_gemm")
+    return out
+
+
+def rowpanel_gemm_ln(a, w_fm, K, bias, res, gamma, beta, row_pad, eps, p_drop, seed):
+    """(sub_out, y, mean, rstd): sub_out = a w^T + bias (T, 512), y = LayerNorm(res + dropout(sub_out)) with pad rows
+    zeroed — add_ln_fwd fused behind the product.  K = 512: the resident-panel kernel, else the streaming one."""
+    T = a.shape[0]
+    dev = a.device
+    assert a.dtype == torch.bfloat16 and a.shape[1] == K and a.stride(1) == 1 and res.stride(1) == 1
+    sub = torch.empty((T, 512), dtype=torch.bfloat16, device=dev)
+    y = torch.empty((T, 512), dtype=torch.bfloat16, device=dev)
+    mean = torch.empty(T, dtype=torch.float32, device=dev)
+    rstd = torch.empty(T, dtype=torch.float32, device=dev)
+    lib = load()
+    if K == 512:
+        rc = lib.skhip_rowpanel_gemm_ln(_ptr(a), a.stride(0), _ptr(w_fm), _ptr(bias), _ptr(res), res.stride(0), _ptr(sub),
+                                        _ptr(gamma), _ptr(beta), _ptr(row_pad), _ptr(y), _ptr(mean), _ptr(rstd), T,
+                                        float(eps), float(p_drop), int(seed), _stream())
+    else:
+        rc = lib.skhip_rowstream_gemm_ln(_ptr(a), a.stride(0), K, _ptr(w_fm), _ptr(bias), _ptr(res), res.stride(0),
+                                         _ptr(sub), _ptr(gamma), _ptr(beta), _ptr(row_pad), _ptr(y), _ptr(mean), _ptr(rstd),
+                                         T, float(eps), float(p_drop), int(seed), _stream())
+    _check(rc, "skhip_rowpanel_gemm_ln" if K == 512 else "skhip_rowstream_gemm_ln")
+    return sub, y, mean, rstd
 
 
 # --------------------------------------------------------------------------- attention

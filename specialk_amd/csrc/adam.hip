@@ -71,6 +71,7 @@ __global__ __launch_bounds__(256) void cast2d_multi_kernel(const uint64_t* __res
   const int t = blockIdx.y;
   const int64_t R = meta[4 * t], C = meta[4 * t + 1], ld = meta[4 * t + 2], flags = meta[4 * t + 3];
   const bool transpose = flags & 1, dst_f32 = flags & 2;
+  const int fm_tiles = (int)((flags >> 2) & 3) * 2;  // 0: row-major destination, else fragment-major with 2 / 4 tiles per group
   const float* s = (const float*)sp[t];
   const int64_t tr = (R + 31) / 32, tc = (C + 31) / 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
@@ -89,7 +90,20 @@ __global__ __launch_bounds__(256) void cast2d_multi_kernel(const uint64_t* __res
       const int64_t nrow = transpose ? C : R, ncol = transpose ? R : C;
       if (orow < nrow && ocol < ncol) {
         const float v = transpose ? tile[tx][ty + 8 * i] : tile[ty + 8 * i][tx];
-        if (dst_f32) ((float*)dp[t])[orow * ld + ocol] = v;
+        if (fm_tiles) {
+          // element (n = orow, k = ocol) of the [nrow][ncol] matrix in the fragment-major layout
+          // [n / (16 T)][k / 32][T][64 lanes][8]: the wave that owns the group's 16 T output columns loads, per
+          // K-step and tile, 1 KB of consecutive bytes; tile ti holds as its row i the group's column
+          // 4 T (i >> 2) + 4 ti + (i & 3), lane (i, gk) the elements k = 8 gk .. 8 gk + 7 of it.
+          const int TT = fm_tiles;
+          const int64_t G = orow / (16 * TT);
+          const int j = (int)(orow % (16 * TT));
+          const int i_row = 4 * (j / (4 * TT)) + (j & 3), ti = (j % (4 * TT)) >> 2;
+          const int kk = (int)(ocol & 31);
+          const int64_t ksteps = (ld > 0 ? ld : ncol) >> 5;  // K-steps of the whole destination (this entry may be a K slice of it)
+          const int64_t idx = ((((G * ksteps + (ocol >> 5)) * TT + ti) * 64) + i_row + 16 * (kk >> 3)) * 8 + (kk & 7);
+          ((bf16_t*)dp[t])[idx] = f32_to_bf16(v);
+        } else if (dst_f32) ((float*)dp[t])[orow * ld + ocol] = v;
         else ((bf16_t*)dp[t])[orow * ld + ocol] = f32_to_bf16(v);
       }
     }

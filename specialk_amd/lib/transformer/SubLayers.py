@@ -45,10 +45,17 @@ class MultiHeadAttention(nn.Module):
                    key_pad=key_pad, causal=bool(causal), dense_mask=dense_mask,
                    scale=1.0 / float(self.attention.temperature),
                    p_attn=self.attention.dropout.p if training else 0.0, want_attn=want_attn, kv_pre=kv_pre)
+        p_out = self.dropout.p if training else 0.0
+        if ops.mha_ln_fusable(q_in, self.fc.weight, self.n_head * self.d_v):
+            # output projection, dropout, residual, LayerNorm and row mask in one launch
+            cfg.update(ln_row_pad=row_pad, ln_eps=self.layer_norm.eps, ln_p=p_out)
+            return ops.call(ops.MHALNFn, q_in, kv_in, self.w_qs.weight, self.w_qs.bias, self.w_ks.weight, self.w_ks.bias,
+                            self.w_vs.weight, self.w_vs.bias, self.fc.weight, self.fc.bias, self.layer_norm.weight,
+                            self.layer_norm.bias, cfg)
         out, attn = ops.call(ops.MHAFn, q_in, kv_in, self.w_qs.weight, self.w_qs.bias, self.w_ks.weight, self.w_ks.bias,
                                     self.w_vs.weight, self.w_vs.bias, self.fc.weight, self.fc.bias, cfg)
-        y = ops.add_ln(out, q_in, self.layer_norm.weight, self.layer_norm.bias, row_pad, self.layer_norm.eps,
-                       self.dropout.p if training else 0.0, res_feeds_x=True)
+        y = ops.add_ln(out, q_in, self.layer_norm.weight, self.layer_norm.bias, row_pad, self.layer_norm.eps, p_out,
+                       res_feeds_x=True)
         return y, attn
 
     # -- reference interface

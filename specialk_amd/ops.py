@@ -87,7 +87,11 @@ def derived_weight(kind, params):
       "cat"  : bf16 [sum R_i][C]   the matrices stacked by rows (one fused projection GEMM),
       "catT" : bf16 [C][sum R_i]   their transposes side by side (K-contiguous weight operand of
                                    the input-gradient GEMMs),
-      "bias" : fp32 [sum n_i]      bias vectors concatenated."""
+      "bias" : fp32 [sum n_i]      bias vectors concatenated,
+      "fm"   : bf16, the matrices stacked by rows ([sum R_i][C]) in the fragment-major layout of the row-panel
+               kernels ([N/64][K/32][4][64][8], see skhip_cast2d_multi; R_i % 64 == 0, C % 64 == 0),
+      "fmT"  : the same of their transposes side by side ([C][sum R_i]: the weight operand of an input-gradient
+               product)."""
     global _derived_tables
     key = (kind,) + tuple(id(p) for p in params)
     d = _derived.get(key)
@@ -99,6 +103,11 @@ def derived_weight(kind, params):
     if kind == "bias":
         total = sum(p.numel() for p in params)
         shape, dt = (total,), torch.float32
+    elif kind in ("fm", "fmT"):
+        C = _as2d(params[0])[1]
+        assert all(_as2d(p)[1] == C and _as2d(p)[0] % 64 == 0 for p in params) and C % 64 == 0
+        total = sum(_as2d(p)[0] for p in params)
+        shape, dt = ((total, C) if kind == "fm" else (C, total)), torch.bfloat16
     else:
         C = _as2d(params[0])[1]
         assert all(_as2d(p)[1] == C for p in params)
@@ -115,6 +124,14 @@ def derived_weight(kind, params):
         if kind == "bias":
             rows.append((p.data_ptr(), d.tensor.data_ptr() + off * esz, 1, p.numel(), total, 2))
             off += p.numel()
+        elif kind == "fm":  # the matrices stacked by rows: each starts a new 64-row group
+            R, C = _as2d(p)
+            rows.append((p.data_ptr(), d.tensor.data_ptr() + off * C * esz, R, C, 0, 2 << 2))
+            off += R
+        elif kind == "fmT":  # their transposes side by side: each is a run of K-steps of every group
+            R, C = _as2d(p)
+            rows.append((p.data_ptr(), d.tensor.data_ptr() + off * 64 * esz, R, C, total, (2 << 2) | 1))
+            off += R
         elif kind == "cat":
             R, C = _as2d(p)
             rows.append((p.data_ptr(), d.tensor.data_ptr() + off * C * esz, R, C, C, 0))
@@ -218,6 +235,29 @@ def _w2d(w):
     return w.reshape(w.shape[0], -1)  # Conv1d(k=1) weights (out,in,1) are linear maps (out,in)
 
 
+_ROWPANEL = os.environ.get("SK_ROWPANEL", "1") != "0"
+_cu_count = {}
+
+
+def _panel_rows_ok(x, T):
+    """Whether T token rows suit the row-panel kernels (one workgroup per 104 rows, one per CU at a time): the
+    workgroups must fill at least 80 % of the rounds of the chip they take — 25.6 k rows are 247 of 256 CUs, 33 k rows
+    would be one full round and a quarter of a second one, where the tiled kernels do better."""
+    if not _ROWPANEL or x.dtype != torch.bfloat16 or x.stride(1) != 1 or x.stride(0) % 8 or x.data_ptr() % 16:
+        return False
+    cus = _cu_count.get(x.device)
+    if cus is None:
+        cus = _cu_count[x.device] = torch.cuda.get_device_properties(x.device).multi_processor_count
+    blocks = -(-T // L.ROWPANEL_ROWS)
+    rounds = -(-blocks // cus)
+    return blocks >= 0.8 * rounds * cus
+
+
+def _panel_weights_ok(Ws, d_in):
+    """Stacked weights (n_i, 512) whose total row count is a multiple of 512: the operand shape of the panel kernel."""
+    return d_in == 512 and all(_as2d(w)[1] == 512 and _as2d(w)[0] % 64 == 0 for w in Ws) and sum(_as2d(w)[0] for w in Ws) % 512 == 0
+
+
 def _input_grad(dy, ldy, Ws, T, d_in, dt, alpha=1.0, aux=None, epilogue=0, add_to=None):
     """dx (T, d_in) = alpha * dy (T, sum n_i; row stride ldy) @ [W_1; W_2; ...] for weights W_i (n_i, d_in).
     bf16: ONE GEMM against the K-contiguous transposed copy; fp32: one exact-fp32 GEMM per weight.
@@ -252,6 +292,12 @@ def _project(x, Ws, bs, out, ldc, dt):
     """out[:, blocks] = x @ W_i^T + b_i for the stacked weights: one fused GEMM in bf16, one GEMM each in fp32."""
     T, d = x.shape
     n_tot = sum(_as2d(w)[0] for w in Ws)
+    if dt == torch.bfloat16 and n_tot >= 1024 and _panel_weights_ok(Ws, d) and _panel_rows_ok(x, T) and ldc % 8 == 0 \
+            and out.data_ptr() % 16 == 0:
+        # several column blocks of 512 against the same rows: the rows are brought on chip once
+        b = derived_weight("bias", bs) if len(bs) > 1 else bs[0].detach()
+        L.rowpanel_gemm(x, derived_weight("fm", Ws), n_tot, bias=b, out=out, ldc=ldc)
+        return
     if dt == torch.bfloat16:
         W = derived_weight("cat", Ws) if len(Ws) > 1 else _w2d(compute_weight(Ws[0], dt))
         b = derived_weight("bias", bs) if len(bs) > 1 else bs[0].detach()
@@ -448,15 +494,19 @@ class FFNFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, W1, b1, W2, b2):
         T, d = x.shape
-        W1c, W2c = _w2d(compute_weight(W1, x.dtype)), _w2d(compute_weight(W2, x.dtype))
-        F = W1c.shape[0]
+        W2c = _w2d(compute_weight(W2, x.dtype))
+        F = _as2d(W1)[0]
         # bf16: the first GEMM also writes the sign pattern of h, one bit per element, which is all the
         # backward of the ReLU needs (the input-gradient GEMM then reads 1/16 of the bytes of h)
         signs = None
         if x.dtype == torch.bfloat16 and F % 64 == 0 and x.stride(0) % 8 == 0 and x.data_ptr() % 16 == 0:
             signs = torch.empty((T, F // 16), dtype=torch.int16, device=x.device)
-        h = L.gemm(L.GEMM_NT, x, W1c, T, F, d, x.stride(0), d, bias=b1.detach(), aux=signs,
-                   epilogue=L.EPI_RELU | (L.EPI_RELU_BITS_OUT if signs is not None else 0))
+        if signs is not None and _panel_weights_ok((W1,), d) and _panel_rows_ok(x, T):
+            h = L.rowpanel_gemm(x, derived_weight("fm", (W1,)), F, bias=b1.detach(), signs=signs,
+                                epilogue=L.EPI_RELU | L.EPI_RELU_BITS_OUT)
+        else:
+            h = L.gemm(L.GEMM_NT, x, _w2d(compute_weight(W1, x.dtype)), T, F, d, x.stride(0), d, bias=b1.detach(), aux=signs,
+                       epilogue=L.EPI_RELU | (L.EPI_RELU_BITS_OUT if signs is not None else 0))
         y = L.gemm(L.GEMM_NT, h, W2c, T, d, F, F, F, bias=b2.detach())
         ctx.save_for_backward(x, h, W1, W2, b1)
         ctx.signs = signs
@@ -470,7 +520,9 @@ class FFNFn(torch.autograd.Function):
         dres = _unalias(dres, dy)
         T, d = x.shape
         F = _as2d(W1)[0]
-        if ctx.signs is not None:
+        if ctx.signs is not None and d == 512 and F % 512 == 0 and _panel_rows_ok(dy, T):
+            dh = L.rowpanel_gemm(dy, derived_weight("fmT", (W2,)), F, signs=ctx.signs, epilogue=L.EPI_RELU_MASK_BITS)
+        elif ctx.signs is not None:
             dh = _input_grad(dy, d, (W2,), T, F, x.dtype, aux=ctx.signs, epilogue=L.EPI_RELU_MASK_BITS)
         else:
             dh = _input_grad(dy, d, (W2,), T, F, x.dtype, aux=h, epilogue=L.EPI_RELU_MASK)
@@ -495,6 +547,19 @@ class MHAFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, q_in, kv_in, Wq, bq, Wk, bk, Wv, bv, Wo, bo, cfg):
+        return _mha_forward(ctx, q_in, kv_in, Wq, bq, Wk, bk, Wv, bv, Wo, bo, cfg, None)
+
+    @staticmethod
+    def backward(ctx, dout, _dP):
+        dres = _residual_grad(dout)
+        dout = dout.contiguous()
+        return _mha_backward(ctx, dout, _unalias(dres, dout), None)
+
+
+def _mha_forward(ctx, q_in, kv_in, Wq, bq, Wk, bk, Wv, bv, Wo, bo, cfg, ln):
+    """MHAFn.forward; ln = (gamma, beta): MHALNFn.forward, which ends with the output projection and the sub-layer
+    tail in one launch and returns (LayerNorm output, attn)."""
+    if True:
         B, Lq, Lk, H, dk, dv = cfg["B"], cfg["Lq"], cfg["Lk"], cfg["H"], cfg["dk"], cfg["dv"]
         dt, dev = q_in.dtype, q_in.device
         d = q_in.shape[1]
@@ -527,16 +592,29 @@ class MHAFn(torch.autograd.Function):
         L.attn_fwd(Q, K, V, O, lse, B, H, Lq, Lk, dk, dv, ldq, ldk, ldv, nv, cfg["scale"], key_pad=cfg["key_pad"],
                    dense_mask=cfg["dense_mask"], causal=cfg["causal"], p_drop=cfg["p_attn"], seed=seed, P_out=P,
                    q_off=cfg.get("q_off"), k_off=cfg.get("k_off"))
-        out = L.gemm(L.GEMM_NT, O, compute_weight(Wo, dt), Tq, d, nv, nv, nv, bias=bo.detach())
-        ctx.save_for_backward(q_in, kv_in, Q, K, V, O, lse, Wq, Wk, Wv, Wo, bq, bk, bv)
         ctx.cfg, ctx.seed, ctx.lds = cfg, seed, (ldq, ldk, ldv)
         if P is not None:
             ctx.mark_non_differentiable(P)
-        return out, P
+        if ln is None:
+            out = L.gemm(L.GEMM_NT, O, compute_weight(Wo, dt), Tq, d, nv, nv, nv, bias=bo.detach())
+            ctx.save_for_backward(q_in, kv_in, Q, K, V, O, lse, Wq, Wk, Wv, Wo, bq, bk, bv)
+            return out, P
+        gamma, beta = ln
+        p_drop = cfg["ln_p"]
+        seed2 = next_seed() if p_drop > 0 else 0
+        sub, y, mean, rstd = L.rowpanel_gemm_ln(O, derived_weight("fm", (Wo,)), nv, bo.detach(), q_in, gamma.detach(),
+                                                beta.detach(), cfg["ln_row_pad"], cfg["ln_eps"], p_drop, seed2)
+        ctx.save_for_backward(q_in, kv_in, Q, K, V, O, lse, Wq, Wk, Wv, Wo, bq, bk, bv, sub, mean, rstd, gamma)
+        ctx.ln_seed = seed2
+        return y, P
 
-    @staticmethod
-    def backward(ctx, dout, _dP):
-        q_in, kv_in, Q, K, V, O, lse, Wq, Wk, Wv, Wo, bq, bk, bv = ctx.saved_tensors
+
+def _mha_backward(ctx, dout, dres, dbo):
+    """MHAFn.backward from the gradient of the output projection's result: dout (contiguous), dres the
+    residual-branch gradient the input gradient is accumulated into (or None), dbo the output bias gradient when the
+    LayerNorm backward already summed it (else it is taken from dout)."""
+    if True:
+        q_in, kv_in, Q, K, V, O, lse, Wq, Wk, Wv, Wo, bq, bk, bv = ctx.saved_tensors[:14]
         cfg = ctx.cfg
         B, Lq, Lk, H, dk, dv = cfg["B"], cfg["Lq"], cfg["Lk"], cfg["H"], cfg["dk"], cfg["dv"]
         dt, dev = q_in.dtype, q_in.device
@@ -544,15 +622,13 @@ class MHAFn(torch.autograd.Function):
         Tq, Tk = q_in.shape[0], kv_in.shape[0]
         nq, nk, nv = H * dk, H * dk, H * dv
         ldq, ldk, ldv = ctx.lds
-        dres = _residual_grad(dout)
-        dout = dout.contiguous()
-        dres = _unalias(dres, dout)
         f32 = torch.float32
         need = ctx.needs_input_grad
         # output projection
         dO = _input_grad(dout, d, (Wo,), Tq, nv, dt)
         dWo, _ = _weight_grad(dout, O, Wo, Tq, need[8])
-        dbo = _bias_grad(dout, Tq, d)
+        if dbo is None:
+            dbo = _bias_grad(dout, Tq, d)
         # attention core
         if cfg["self_attn"]:
             dqkv = torch.empty((Tq, nq + nk + nv), dtype=dt, device=dev)
@@ -609,6 +685,34 @@ class MHAFn(torch.autograd.Function):
             dq_in = _input_grad(dQ, lddq, (Wq,), Tq, d, dt, add_to=dres)  # accumulates into dres in place
             dkv_in = _input_grad(dkv, lddk, (Wk, Wv), Tk, d, dt)
         return dq_in, dkv_in, dWq, dbq, dWk, dbk, dWv, dbv, dWo, dbo, None
+
+
+class MHALNFn(torch.autograd.Function):
+    """MHAFn followed by the sub-layer tail `layer_norm(dropout(fc(output)) + residual)` with pad rows zeroed
+    (lib/transformer/SubLayers.py:62-63, Layers.py:22,50,55): the output projection, dropout, residual (= q_in),
+    LayerNorm and row mask are ONE launch (skhip_rowpanel_gemm_ln).  cfg carries ln_row_pad, ln_eps, ln_p besides
+    MHAFn's entries.  Returns (LayerNorm output (B*Lq, d), attn or None)."""
+
+    @staticmethod
+    def forward(ctx, q_in, kv_in, Wq, bq, Wk, bk, Wv, bv, Wo, bo, gamma, beta, cfg):
+        return _mha_forward(ctx, q_in, kv_in, Wq, bq, Wk, bk, Wv, bv, Wo, bo, cfg, (gamma, beta))
+
+    @staticmethod
+    def backward(ctx, dy, _dP):
+        q_in = ctx.saved_tensors[0]
+        sub, mean, rstd, gamma = ctx.saved_tensors[14:18]
+        cfg = ctx.cfg
+        _check_residual_handoff()
+        dx, dres, dg, db, dxs = L.add_ln_bwd(dy.contiguous(), sub, q_in, gamma.detach(), cfg["ln_row_pad"], mean, rstd,
+                                             cfg["ln_p"], ctx.ln_seed, want_dx_colsum=True)
+        grads = _mha_backward(ctx, dx, _unalias(dres, dx), dxs)
+        return grads[:10] + (dg, db, None)
+
+
+def mha_ln_fusable(q_in, Wo, n_v):
+    """Whether MHALNFn's one-launch tail applies: bf16, d_model = h * d_v = 512, row count that fills the chip."""
+    return (q_in.dtype == torch.bfloat16 and q_in.shape[1] == 512 and n_v == 512 and tuple(Wo.shape) == (512, 512)
+            and _panel_rows_ok(q_in, q_in.shape[0]))
 
 
 class CrossKVShared:
