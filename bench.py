@@ -140,13 +140,31 @@ def gemm_roofline(m, opt, batch, steps):
         fl = sum(2.0 * M * N * K * frac.get(K, 1.0) for _, _, _, M, N, K, *_ in problems)
         records.append((e0, e1, fl, problems[0][0].dtype))
 
-    L.gemm, L.gemm_grouped_tn = timed, timed_grouped
+    orig_panel, orig_panel_ln = L.rowpanel_gemm, L.rowpanel_gemm_ln
+
+    def timed_panel(a, w_fm, N, *args, **kw):  # (T, 512) x (N, 512)^T
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = orig_panel(a, w_fm, N, *args, **kw)
+        e1.record()
+        records.append((e0, e1, 2.0 * a.shape[0] * N * 512 * frac.get(a.shape[0], 1.0), a.dtype))
+        return out
+
+    def timed_panel_ln(a, *args, **kw):  # the output projection with its LayerNorm tail: credited as the product alone
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = orig_panel_ln(a, *args, **kw)
+        e1.record()
+        records.append((e0, e1, 2.0 * a.shape[0] * 512 * 512 * frac.get(a.shape[0], 1.0), a.dtype))
+        return out
+
+    L.gemm, L.gemm_grouped_tn, L.rowpanel_gemm, L.rowpanel_gemm_ln = timed, timed_grouped, timed_panel, timed_panel_ln
     try:
         for _ in range(steps):
             train_step(m, opt, batch, None)
         torch.cuda.synchronize()
     finally:
-        L.gemm, L.gemm_grouped_tn = orig, orig_grouped
+        L.gemm, L.gemm_grouped_tn, L.rowpanel_gemm, L.rowpanel_gemm_ln = orig, orig_grouped, orig_panel, orig_panel_ln
     ms = sum(e0.elapsed_time(e1) for e0, e1, _, _ in records)
     flops = sum(f for _, _, f, _ in records)
     n = len(records)
@@ -166,7 +184,7 @@ def gemm_roofline(m, opt, batch, steps):
 def _roofline_dict(flops, ms, n, steps):
     return dict(bound="mfma", achieved=round(flops / (ms * 1e-3) / 1e12, 2), peak=MFMA_BF16_PEAK_TFLOPS,
                 unit="TFLOP/s", frac=round(flops / (ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4), traffic=None,
-                kernel="b16x/b16g/b16::gemm_kernel + b16x::gemm_grouped_tn_kernel (bf16 MFMA GEMMs, all layouts)", launches_per_step=n // steps,
+                kernel="b16x/b16g/b16::gemm_kernel + b16x::gemm_grouped_tn_kernel + rp::panel_kernel (bf16 MFMA GEMMs, all layouts; the panel kernel's LayerNorm tail is inside its time)", launches_per_step=n // steps,
                 avg_launch_us=round(ms * 1e3 / n, 2), avg_algorithmic_gflop_per_launch=round(flops / n / 1e9, 3))
 
 

@@ -201,18 +201,17 @@ int skhip_add_ln_bwd(const void* dy, const void* x, const void* res, const float
  *
  * skhip_rowpanel_gemm: c [T][N] = epilogue(a [T][512] w^T), w [N][512] fragment-major, N a multiple of 512 — nn.Linear /
  * Conv1d(k=1) forward and input gradient with a 512-deep contraction (SubLayers.py:46-48,62,73,80 and their autograd
- * backward).  epilogue: 0, SK_EPI_BIAS, SK_EPI_BIAS | SK_EPI_RELU | SK_EPI_RELU_BITS_OUT (signs receives the pattern,
- * skhip_gemm's format), SK_EPI_RELU_MASK_BITS (signs is read), SK_EPI_ACCUM (c += ...).
+ * backward).  epilogue: 0, SK_EPI_BIAS, SK_EPI_BIAS | SK_EPI_RELU | SK_EPI_RELU_BITS_OUT (signs receives the pattern),
+ * SK_EPI_RELU_MASK_BITS (signs is read), SK_EPI_ACCUM (c += ...).  The pattern has the row-panel kernels' OWN layout
+ * (two bits per element in lane order, skhip_rowpanel_pattern_bytes(T, N) bytes, not skhip_gemm's): it is only read
+ * back by this entry point, in a call with the same T and N.
  * skhip_rowpanel_gemm_ln: N = 512 and the sub-layer tail as the epilogue — replaces `self.layer_norm(self.dropout(
  * self.fc(output)) + residual)` (SubLayers.py:62-63) = skhip_gemm + skhip_add_ln_fwd:  sub_out = a w^T + bias [T][512]
  * (stored: the backward pass reads it), y = LayerNorm(res + dropout_p(sub_out)) gamma + beta with pad rows zeroed,
- * mean / rstd [T] as skhip_add_ln_fwd leaves them.
- * skhip_rowstream_gemm / _ln: the same two forms for N = 512 and a contraction K that is a multiple of 256 (w [512][K]
- * fragment-major), the rows' K extent streamed through LDS: the feed-forward w_2 with its LayerNorm (SubLayers.py:81-84),
- * its input gradient accumulated into the residual-branch gradient (accumulate != 0: c += a w^T), the input gradient of
- * the stacked q | k | v projections.                                                                          */
+ * mean / rstd [T] as skhip_add_ln_fwd leaves them.                                                           */
 #define SK_ROWPANEL_ROWS 104
 int skhip_rowpanel_rows(void);
+int64_t skhip_rowpanel_pattern_bytes(int64_t T, int64_t N);
 /* Diagnostics (no counterpart in the reference): with a device buffer of ceil(T / SK_ROWPANEL_ROWS) * 8 * 32 uint64 set,
  * every wave of the row-panel kernels leaves shader-clock readings at its phase boundaries there; NULL (the start
  * value) turns it off.  Process-wide, not thread-safe.                                                         */
@@ -223,12 +222,6 @@ int skhip_rowpanel_gemm_ln(const void* a, int64_t lda, const void* w_fm, const f
                            int64_t ldres, void* sub_out, const float* gamma, const float* beta,
                            const uint8_t* row_pad, void* y, float* mean, float* rstd, int64_t T, float eps,
                            float p_drop, uint64_t seed, void* stream);
-int skhip_rowstream_gemm(const void* a, int64_t lda, int64_t K, const void* w_fm, const float* bias, void* c,
-                         int64_t ldc, int accumulate, int64_t T, void* stream);
-int skhip_rowstream_gemm_ln(const void* a, int64_t lda, int64_t K, const void* w_fm, const float* bias,
-                            const void* res, int64_t ldres, void* sub_out, const float* gamma, const float* beta,
-                            const uint8_t* row_pad, void* y, float* mean, float* rstd, int64_t T, float eps,
-                            float p_drop, uint64_t seed, void* stream);
 
 /* ---- embeddings ----------------------------------------------------------------------
  * out[t] = word_emb[seq[t]] + pos_table[pos[t]]   (lib/transformer/Models.py:117-118,

@@ -15,7 +15,7 @@ GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
 EPI_BIAS, EPI_RELU, EPI_RELU_MASK, EPI_ACCUM, EPI_RELU_BITS_OUT, EPI_RELU_MASK_BITS, EPI_ROWSTATS = 1, 2, 4, 8, 16, 32, 64
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libspecialk_hip.so")
+LIB_PATH = os.environ.get("SKHIP_LIB") or os.path.join(_HERE, "libspecialk_hip.so")  # (SKHIP_LIB: a diagnostics build)
 
 # every symbol include/specialk_hip.h declares
 EXPORTS = [
@@ -25,7 +25,7 @@ EXPORTS = [
     "skhip_decode_attn", "skhip_beam_topk_ws_bytes", "skhip_beam_topk", "skhip_beam_update", "skhip_gather_rows",
     "skhip_decode_stack_ws_bytes", "skhip_decode_stack", "skhip_beam_topk_stats", "skhip_beam_step",
     "skhip_softmax_rows", "skhip_conv_windows", "skhip_cnn_head", "skhip_collate", "skhip_set_reserved_cus",
-    "skhip_rowpanel_rows", "skhip_rowpanel_set_stamps", "skhip_rowpanel_gemm", "skhip_rowpanel_gemm_ln", "skhip_rowstream_gemm", "skhip_rowstream_gemm_ln",
+    "skhip_rowpanel_rows", "skhip_rowpanel_pattern_bytes", "skhip_rowpanel_set_stamps", "skhip_rowpanel_gemm", "skhip_rowpanel_gemm_ln",
 ]
 
 _lib = None
@@ -82,10 +82,10 @@ def load():
     lib.skhip_decode_stack.argtypes = [c_p, c_int] + [c_p] * 11 + [c_i64] + [c_int] * 8 + [c_f32, c_f32, c_int, c_p]
     lib.skhip_gather_rows.argtypes = [c_p] * 3 + [c_i64] * 4 + [c_int, c_p]
     lib.skhip_rowpanel_set_stamps.argtypes = [c_p]
+    lib.skhip_rowpanel_pattern_bytes.argtypes = [c_i64, c_i64]
+    lib.skhip_rowpanel_pattern_bytes.restype = c_i64
     lib.skhip_rowpanel_gemm.argtypes = [c_p, c_i64, c_p, c_p, c_p, c_i64, c_p, c_i64, c_i64, c_int, c_p]
     lib.skhip_rowpanel_gemm_ln.argtypes = [c_p, c_i64, c_p, c_p, c_p, c_i64] + [c_p] * 7 + [c_i64, c_f32, c_f32, c_u64, c_p]
-    lib.skhip_rowstream_gemm.argtypes = [c_p, c_i64, c_i64, c_p, c_p, c_p, c_i64, c_int, c_i64, c_p]
-    lib.skhip_rowstream_gemm_ln.argtypes = [c_p, c_i64, c_i64, c_p, c_p, c_p, c_i64] + [c_p] * 7 + [c_i64, c_f32, c_f32, c_u64, c_p]
     for name in EXPORTS:
         getattr(lib, name)  # AttributeError here means header and library disagree
     _lib = lib
@@ -228,6 +228,11 @@ def rowpanel_set_stamps(buf):
     _check(load().skhip_rowpanel_set_stamps(_ptr(buf)), "skhip_rowpanel_set_stamps")
 
 
+def rowpanel_pattern(T, N, device):
+    """Buffer for the ReLU pattern of a (T, N) row-panel product (the kernels' own layout)."""
+    return torch.empty(int(load().skhip_rowpanel_pattern_bytes(T, N)) // 4, dtype=torch.int32, device=device)
+
+
 def rowpanel_gemm(a, w_fm, N, bias=None, out=None, ldc=None, signs=None, epilogue=0):
     """out (T, N) = epilogue(a (T, 512; any row stride) w^T) with w (N, 512) fragment-major (ops.derived_weight "fm")."""
     T = a.shape[0]
@@ -241,38 +246,20 @@ def rowpanel_gemm(a, w_fm, N, bias=None, out=None, ldc=None, signs=None, epilogu
     return out
 
 
-def rowstream_gemm(a, w_fm, K, bias=None, out=None, ldc=512, accumulate=False):
-    """out (T, 512) (+)= a (T, K; any row stride) w^T with w (512, K) fragment-major."""
-    T = a.shape[0]
-    assert a.dtype == torch.bfloat16 and a.shape[1] == K and a.stride(1) == 1
-    if out is None:
-        assert not accumulate
-        out = torch.empty((T, 512), dtype=torch.bfloat16, device=a.device)
-    _check(load().skhip_rowstream_gemm(_ptr(a), a.stride(0), K, _ptr(w_fm), _ptr(bias), _ptr(out), ldc, int(accumulate), T,
-                                       _stream()), "skhip_rowstream_gemm")
-    return out
-
-
-def rowpanel_gemm_ln(a, w_fm, K, bias, res, gamma, beta, row_pad, eps, p_drop, seed):
+def rowpanel_gemm_ln(a, w_fm, bias, res, gamma, beta, row_pad, eps, p_drop, seed):
     """(sub_out, y, mean, rstd): sub_out = a w^T + bias (T, 512), y = LayerNorm(res + dropout(sub_out)) with pad rows
-    zeroed — add_ln_fwd fused behind the product.  K = 512: the resident-panel kernel, else the streaming one."""
+    zeroed — add_ln_fwd fused behind the product (w (512, 512) fragment-major)."""
     T = a.shape[0]
     dev = a.device
-    assert a.dtype == torch.bfloat16 and a.shape[1] == K and a.stride(1) == 1 and res.stride(1) == 1
+    assert a.dtype == torch.bfloat16 and a.shape[1] == 512 and a.stride(1) == 1 and res.stride(1) == 1
     sub = torch.empty((T, 512), dtype=torch.bfloat16, device=dev)
     y = torch.empty((T, 512), dtype=torch.bfloat16, device=dev)
     mean = torch.empty(T, dtype=torch.float32, device=dev)
     rstd = torch.empty(T, dtype=torch.float32, device=dev)
-    lib = load()
-    if K == 512:
-        rc = lib.skhip_rowpanel_gemm_ln(_ptr(a), a.stride(0), _ptr(w_fm), _ptr(bias), _ptr(res), res.stride(0), _ptr(sub),
-                                        _ptr(gamma), _ptr(beta), _ptr(row_pad), _ptr(y), _ptr(mean), _ptr(rstd), T,
-                                        float(eps), float(p_drop), int(seed), _stream())
-    else:
-        rc = lib.skhip_rowstream_gemm_ln(_ptr(a), a.stride(0), K, _ptr(w_fm), _ptr(bias), _ptr(res), res.stride(0),
-                                         _ptr(sub), _ptr(gamma), _ptr(beta), _ptr(row_pad), _ptr(y), _ptr(mean), _ptr(rstd),
-                                         T, float(eps), float(p_drop), int(seed), _stream())
-    _check(rc, "skhip_rowpanel_gemm_ln" if K == 512 else "skhip_rowstream_gemm_ln")
+    rc = load().skhip_rowpanel_gemm_ln(_ptr(a), a.stride(0), _ptr(w_fm), _ptr(bias), _ptr(res), res.stride(0), _ptr(sub),
+                                       _ptr(gamma), _ptr(beta), _ptr(row_pad), _ptr(y), _ptr(mean), _ptr(rstd), T,
+                                       float(eps), float(p_drop), int(seed), _stream())
+    _check(rc, "skhip_rowpanel_gemm_ln")
     return sub, y, mean, rstd
 
 

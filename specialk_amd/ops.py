@@ -498,10 +498,12 @@ class FFNFn(torch.autograd.Function):
         F = _as2d(W1)[0]
         # bf16: the first GEMM also writes the sign pattern of h, one bit per element, which is all the
         # backward of the ReLU needs (the input-gradient GEMM then reads 1/16 of the bytes of h)
-        signs = None
+        signs, panel = None, False
         if x.dtype == torch.bfloat16 and F % 64 == 0 and x.stride(0) % 8 == 0 and x.data_ptr() % 16 == 0:
-            signs = torch.empty((T, F // 16), dtype=torch.int16, device=x.device)
-        if signs is not None and _panel_weights_ok((W1,), d) and _panel_rows_ok(x, T):
+            panel = _panel_weights_ok((W1,), d) and _panel_rows_ok(x, T)
+            # (the row-panel kernels keep the pattern in a layout of their own, which only they read back)
+            signs = L.rowpanel_pattern(T, F, x.device) if panel else torch.empty((T, F // 16), dtype=torch.int16, device=x.device)
+        if panel:
             h = L.rowpanel_gemm(x, derived_weight("fm", (W1,)), F, bias=b1.detach(), signs=signs,
                                 epilogue=L.EPI_RELU | L.EPI_RELU_BITS_OUT)
         else:
@@ -509,7 +511,7 @@ class FFNFn(torch.autograd.Function):
                        epilogue=L.EPI_RELU | (L.EPI_RELU_BITS_OUT if signs is not None else 0))
         y = L.gemm(L.GEMM_NT, h, W2c, T, d, F, F, F, bias=b2.detach())
         ctx.save_for_backward(x, h, W1, W2, b1)
-        ctx.signs = signs
+        ctx.signs, ctx.signs_panel = signs, panel
         return y
 
     @staticmethod
@@ -520,9 +522,9 @@ class FFNFn(torch.autograd.Function):
         dres = _unalias(dres, dy)
         T, d = x.shape
         F = _as2d(W1)[0]
-        if ctx.signs is not None and d == 512 and F % 512 == 0 and _panel_rows_ok(dy, T):
+        if ctx.signs_panel and _panel_rows_ok(dy, T):
             dh = L.rowpanel_gemm(dy, derived_weight("fmT", (W2,)), F, signs=ctx.signs, epilogue=L.EPI_RELU_MASK_BITS)
-        elif ctx.signs is not None:
+        elif ctx.signs is not None and not ctx.signs_panel:
             dh = _input_grad(dy, d, (W2,), T, F, x.dtype, aux=ctx.signs, epilogue=L.EPI_RELU_MASK_BITS)
         else:
             dh = _input_grad(dy, d, (W2,), T, F, x.dtype, aux=h, epilogue=L.EPI_RELU_MASK)
@@ -602,7 +604,7 @@ def _mha_forward(ctx, q_in, kv_in, Wq, bq, Wk, bk, Wv, bv, Wo, bo, cfg, ln):
         gamma, beta = ln
         p_drop = cfg["ln_p"]
         seed2 = next_seed() if p_drop > 0 else 0
-        sub, y, mean, rstd = L.rowpanel_gemm_ln(O, derived_weight("fm", (Wo,)), nv, bo.detach(), q_in, gamma.detach(),
+        sub, y, mean, rstd = L.rowpanel_gemm_ln(O, derived_weight("fm", (Wo,)), bo.detach(), q_in, gamma.detach(),
                                                 beta.detach(), cfg["ln_row_pad"], cfg["ln_eps"], p_drop, seed2)
         ctx.save_for_backward(q_in, kv_in, Q, K, V, O, lse, Wq, Wk, Wv, Wo, bq, bk, bv, sub, mean, rstd, gamma)
         ctx.ln_seed = seed2

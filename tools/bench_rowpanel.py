@@ -54,21 +54,19 @@ def main():
     def par(n, k):
         return torch.nn.Parameter((torch.randn(n, k, generator=g) * k ** -0.5).to(dev))
 
-    x512, x2048, x1536 = act(512), act(2048), act(1536)
+    x512 = act(512)
     out512 = [torch.empty(T, 512, dtype=bf, device=dev) for _ in range(NB)]
     out2048 = [torch.empty(T, 2048, dtype=bf, device=dev) for _ in range(NB)]
     out1536 = [torch.empty(T, 1536, dtype=bf, device=dev) for _ in range(NB)]
     signs = [torch.empty(T, F // 16, dtype=torch.int16, device=dev) for _ in range(NB)]
+    pats = [L.rowpanel_pattern(T, F, dev) for _ in range(NB)]
     W1, W2, Wo, Wqkv = par(F, d), par(d, F), par(d, d), par(1536, d)
     b1, b2, b3 = torch.zeros(F, device=dev), torch.zeros(d, device=dev), torch.zeros(1536, device=dev)
     gamma, beta = torch.ones(d, device=dev), torch.zeros(d, device=dev)
     c = {k: ops.compute_weight(v, bf) for k, v in dict(W1=W1, W2=W2, Wo=Wo, Wqkv=Wqkv).items()}
     W2t = ops.derived_weight("catT", [W2])   # (F, d)^T ... K-contiguous operand of dz W2
-    W1t = ops.derived_weight("catT", [W1])
     f = dict(W1=ops.derived_weight("fm", [W1]), W2=ops.derived_weight("fm", [W2]), Wo=ops.derived_weight("fm", [Wo]),
-             Wqkv=ops.derived_weight("fm", [Wqkv]), W2T=ops.derived_weight("fmT", [W2]), W1T=ops.derived_weight("fmT", [W1]),
-             WqkvT=ops.derived_weight("fmT", [Wqkv]))
-    WqkvT_tiled = ops.derived_weight("catT", [Wqkv])
+             Wqkv=ops.derived_weight("fm", [Wqkv]), W2T=ops.derived_weight("fmT", [W2]))
     RB = L.EPI_RELU | L.EPI_RELU_BITS_OUT
     rows = []
 
@@ -80,10 +78,10 @@ def main():
     fl = lambda n, k: 2.0 * T * n * k
     add("w_1: N 2048 K 512 bias relu pattern", fl(F, d),
         lambda i: L.gemm(L.GEMM_NT, x512[i], c["W1"], T, F, d, d, d, out=out2048[i], ldc=F, bias=b1, aux=signs[i], epilogue=RB),
-        lambda i: L.rowpanel_gemm(x512[i], f["W1"], F, bias=b1, out=out2048[i], ldc=F, signs=signs[i], epilogue=RB))
+        lambda i: L.rowpanel_gemm(x512[i], f["W1"], F, bias=b1, out=out2048[i], ldc=F, signs=pats[i], epilogue=RB))
     add("dz w_2: N 2048 K 512 masked", fl(F, d),
         lambda i: L.gemm(L.GEMM_NT, x512[i], W2t, T, F, d, d, d, out=out2048[i], ldc=F, aux=signs[i], epilogue=L.EPI_RELU_MASK_BITS),
-        lambda i: L.rowpanel_gemm(x512[i], f["W2T"], F, out=out2048[i], ldc=F, signs=signs[i], epilogue=L.EPI_RELU_MASK_BITS))
+        lambda i: L.rowpanel_gemm(x512[i], f["W2T"], F, out=out2048[i], ldc=F, signs=pats[i], epilogue=L.EPI_RELU_MASK_BITS))
     add("q|k|v: N 1536 K 512 bias", fl(1536, d),
         lambda i: L.gemm(L.GEMM_NT, x512[i], c["Wqkv"], T, 1536, d, d, d, out=out1536[i], ldc=1536, bias=b3),
         lambda i: L.rowpanel_gemm(x512[i], f["Wqkv"], 1536, bias=b3, out=out1536[i], ldc=1536))
@@ -99,15 +97,14 @@ def main():
         L.add_ln_fwd(sub, x512[(i + 1) % NB], gamma, beta, None, 1e-5, 0.1, 1234)
 
     add("fc + LayerNorm: N 512 K 512", fl(d, d), lambda i: tiled_ln(i, x512, c["Wo"], d),
-        lambda i: L.rowpanel_gemm_ln(x512[i], f["Wo"], d, b2, x512[(i + 1) % NB], gamma, beta, None, 1e-5, 0.1, 1234))
-    add("w_2 + LayerNorm: N 512 K 2048", fl(d, F), lambda i: tiled_ln(i, x2048, c["W2"], F),
-        lambda i: L.rowpanel_gemm_ln(x2048[i], f["W2"], F, b2, x512[(i + 1) % NB], gamma, beta, None, 1e-5, 0.1, 1234))
-    add("dh w_1: N 512 K 2048 accumulate", fl(d, F),
-        lambda i: L.gemm(L.GEMM_NT, x2048[i], W1t, T, d, F, F, F, out=out512[i], ldc=d, epilogue=L.EPI_ACCUM),
-        lambda i: L.rowstream_gemm(x2048[i], f["W1T"], F, out=out512[i], accumulate=True))
-    add("d(q|k|v) W: N 512 K 1536 accumulate", fl(d, 1536),
-        lambda i: L.gemm(L.GEMM_NT, x1536[i], WqkvT_tiled, T, d, 1536, 1536, 1536, out=out512[i], ldc=d, epilogue=L.EPI_ACCUM),
-        lambda i: L.rowstream_gemm(x1536[i], f["WqkvT"], 1536, out=out512[i], accumulate=True))
+        lambda i: L.rowpanel_gemm_ln(x512[i], f["Wo"], b2, x512[(i + 1) % NB], gamma, beta, None, 1e-5, 0.1, 1234))
+    Wkv = par(6144, d)
+    b4 = torch.zeros(6144, device=dev)
+    out6144 = [torch.empty(T, 6144, dtype=bf, device=dev) for _ in range(2)]
+    ckv, fkv = ops.compute_weight(Wkv, bf), ops.derived_weight("fm", [Wkv])
+    add("k|v of 6 layers: N 6144 K 512 bias", fl(6144, d),
+        lambda i: L.gemm(L.GEMM_NT, x512[i], ckv, T, 6144, d, d, d, out=out6144[i % 2], ldc=6144, bias=b4),
+        lambda i: L.rowpanel_gemm(x512[i], fkv, 6144, bias=b4, out=out6144[i % 2], ldc=6144))
 
     print(f"rows {T}: microseconds per call (TFLOP/s)")
     print(f"{'product':44s} {'tiled':>16s} {'row panel':>16s}")

@@ -19,13 +19,12 @@ g = torch.Generator().manual_seed(0)
 bf = torch.bfloat16
 nblk = (T + 103) // 104
 x512 = (torch.randn(T, 512, generator=g) * 0.5).to(bf).to(dev)
-x2048 = (torch.randn(T, 2048, generator=g) * 0.5).to(bf).to(dev)
 W1 = torch.nn.Parameter((torch.randn(F, d, generator=g) * d ** -0.5).to(dev))
 W2 = torch.nn.Parameter((torch.randn(d, F, generator=g) * F ** -0.5).to(dev))
 b1, b2 = torch.zeros(F, device=dev), torch.zeros(d, device=dev)
 gamma, beta = torch.ones(d, device=dev), torch.zeros(d, device=dev)
-signs = torch.empty(T, F // 16, dtype=torch.int16, device=dev)
-f1, f2 = ops.derived_weight("fm", [W1]), ops.derived_weight("fm", [W2])
+signs = L.rowpanel_pattern(T, F, dev)
+f1 = ops.derived_weight("fm", [W1])
 out2048 = torch.empty(T, F, dtype=bf, device=dev)
 stamps = torch.zeros(nblk * 8 * 32, dtype=torch.int64, device=dev)
 
@@ -67,6 +66,4 @@ RB = L.EPI_RELU | L.EPI_RELU_BITS_OUT
 run("panel N 2048 relu pattern (start, prologue, [K loop, epilogue] x 4)",
     lambda: L.rowpanel_gemm(x512, f1, F, bias=b1, out=out2048, ldc=F, signs=signs, epilogue=RB), 10)
 run("panel N 512 + LayerNorm (start, prologue, K loop, tail)",
-    lambda: L.rowpanel_gemm_ln(x512, ops.derived_weight("fm", [torch.nn.Parameter(W1[:512].detach().clone())]), 512, b2, x512, gamma, beta, None, 1e-5, 0.1, 1), 4)
-run("stream K 2048 + LayerNorm (start, prologue, [chunk, barrier + loads] x 8)",
-    lambda: L.rowpanel_gemm_ln(x2048, f2, F, b2, x512, gamma, beta, None, 1e-5, 0.1, 1), 18)
+    lambda: L.rowpanel_gemm_ln(x512, ops.derived_weight("fm", [torch.nn.Parameter(W1[:512].detach().clone())]), b2, x512, gamma, beta, None, 1e-5, 0.1, 1), 4)
