@@ -184,3 +184,113 @@ def test_kept_weights_follow_parameter_updates():
     assert not torch.equal(x2, x1)
     assert torch.equal(x2, first_output(BeamDecoder(m, 5, 6, use_graph=False, use_stack=True)))
 
+
+
+def test_stack_step_matches_bf16_oracle():
+    """The one-launch stack against the ORACLE (not against this package's other decode path): at every step of a
+    beam search over 12 sentences x 5 beams, the decoder output of each live beam row equals, within the bf16 bar of
+    2e-2, the oracle's decoder forward pass over that row's whole prefix (Translator.py:113-138 re-runs the decoder on
+    the prefix every step; Models.py:167-199) in its bf16-storage mode, last position; and where the oracle's best
+    continuation of a sentence leads its second best by a margin, the search picked exactly that (beam, token)."""
+    import numpy as np
+    from oracle import transformer_np as O
+    from specialk_amd.decode import BeamDecoder
+    n, bm, n_layers, V = 12, 5, 2, 1000
+    m = build(n_layers, vocab=V)
+    src, pos = batch(n, 3, 17, V, 33)
+    dec = BeamDecoder(m, bm, 10, use_graph=False, use_stack=True)
+    dec.trace = []
+    dec.run(src, pos, 1)
+    assert dec.used_stack and len(dec.trace) == 10
+    w = {k: v.detach().float().cpu().numpy() for k, v in m.state_dict().items()}
+    cfg = O.Config(n_layers, 8, 64, 64, 512, 2048)
+    src_np, pos_np = src.cpu().numpy(), pos.cpu().numpy()
+    with O.bf16_storage():
+        enc = O.encoder_fwd(w, cfg, src_np, pos_np)[0]
+    gen = O.round_bf16(w["generator.weight"]).astype(np.float64)
+    prefixes = [[[O.SOS]] + [None] * (bm - 1) for _ in range(n)]   # step 1 expands beam 0 only (Beam.py:29-32, 51-54)
+    live = [True] * n
+    scores_prev = np.zeros((n, bm))
+    worst, checked = 0.0, 0
+    for step, (x, new_scores, prev, new_tok) in enumerate(dec.trace):
+        rows = [(s, k) for s in range(n) if live[s] for k in range(bm) if prefixes[s][k] is not None]
+        t = step + 1
+        tgt = np.array([prefixes[s][k] for s, k in rows], dtype=np.int64)
+        assert tgt.shape[1] == t
+        tpos = np.tile(np.arange(1, t + 1, dtype=np.int64), (len(rows), 1))
+        sidx = [s for s, _ in rows]
+        with O.bf16_storage():
+            out = O.decoder_fwd(w, cfg, tgt, tpos, src_np[sidx], enc[sidx])[0][:, -1]
+        got = x.float().cpu().numpy()[[s * bm + k for s, k in rows]]
+        err = float(np.abs(got - out).max() / np.abs(out).max())
+        worst = max(worst, err)
+        assert err <= 2e-2, (step, err)
+        # the search's choice against the oracle's: log-softmax of the generator's logits (no x_logit_scale,
+        # Translator.py:137) on the oracle's decoder output, plus the running beam scores (Beam.py:55-63)
+        logits = O.round_bf16(out).astype(np.float64) @ gen.T
+        logp = logits - np.log(np.exp(logits - logits.max(1, keepdims=True)).sum(1, keepdims=True)) - logits.max(1, keepdims=True)
+        prev_h, tok_h, sc_h = prev.cpu().numpy(), new_tok.cpu().numpy(), new_scores.cpu().numpy()
+        at = 0
+        for s in range(n):
+            if not live[s]:
+                continue
+            ks = [k for k in range(bm) if prefixes[s][k] is not None]
+            cand = np.stack([scores_prev[s, k] + logp[at + i] for i, k in enumerate(ks)])   # [beams][V]
+            at += len(ks)
+            flat = cand.reshape(-1)
+            order = np.argsort(-flat)[:2]
+            if flat[order[0]] - flat[order[1]] > 0.05:
+                checked += 1
+                assert (ks[order[0] // V], order[0] % V) == (int(prev_h[s, 0]), int(tok_h[s, 0])), (step, s)
+            new = [prefixes[s][int(prev_h[s, k])] + [int(tok_h[s, k])] for k in range(bm)]
+            prefixes[s], scores_prev[s] = new, sc_h[s]
+            if tok_h[s, 0] == O.EOS:   # Beam.done: the sentence's state is frozen from here on (Beam.py:74-77)
+                live[s] = False
+    assert checked >= 30, checked
+    print(f"worst relative difference to the bf16-mode oracle over {len(dec.trace)} steps: {worst:.4f}; "
+          f"{checked} (step, sentence) choices checked against the oracle's")
+
+
+def test_full_size_decode_stack_against_op_by_op():
+    """The decode configuration at full size — 128 sentences x 5 beams = 640 rows, 150 steps, 6 + 6 layers, V = 35 000,
+    source lengths U[12, 42].  (1) Through the one-launch stack replayed from HIP graphs: two runs give the same bits,
+    the stack's error word stays 0 (BeamDecoder.run raises otherwise), n-best scores are ordered.  (2) Against the
+    op-by-op path of the same model with that path's choices forced onto the stack (so that both see the same 150
+    histories): every step's decoder output within 2e-2.  (3) Unforced, the two searches are compared for the record
+    only: random weights leave near-ties that a different bf16 summation order breaks differently at some step, after
+    which two searches are different searches."""
+    import sys
+    from conftest import ROOT
+    sys.path.insert(0, ROOT)
+    import bench
+    from specialk_amd.decode import BeamDecoder
+    cfg = dict(bench.CONFIGS["cfg2"]); cfg["hi"] = 150
+    m, _ = bench.build(cfg, torch.bfloat16, DEV)
+    m.eval()
+    g = torch.Generator().manual_seed(3)
+    s, sp = bench.make_batch(g, 128, 12, 42, cfg["vocab"])
+    s, sp = s.to(DEV), sp.to(DEV)
+    dec = BeamDecoder(m, 5, 150)
+    h1, sc1 = dec.run(s, sp, 3)
+    assert dec.used_stack and dec.last_steps == 150
+    h2, sc2 = dec.run(s, sp, 3)
+    assert h1 == h2 and all(torch.equal(a, b) for a, b in zip(sc1, sc2))
+    assert all(len(h) == 3 and all(1 <= len(x) <= 150 for x in h) for h in h1)
+    assert all(bool((x[:-1] >= x[1:]).all()) for x in sc1)
+    ref = BeamDecoder(m, 5, 150, use_graph=False, use_stack=False)
+    ref.trace = []
+    h0, _ = ref.run(s, sp, 3)
+    assert not ref.used_stack and len(ref.trace) == 150
+    got = BeamDecoder(m, 5, 150, use_graph=False, use_stack=True)
+    got.trace, got.forced = [], [t[1:] for t in ref.trace]
+    hf, _ = got.run(s, sp, 3)
+    assert got.used_stack and hf == h0
+    worst = 0.0
+    for step, (a, b) in enumerate(zip(got.trace, ref.trace)):
+        xa, xb = a[0].float(), b[0].float()
+        err = float((xa - xb).abs().max() / xb.abs().max())
+        worst = max(worst, err)
+        assert err <= 2e-2, (step, err)
+    same = sum(a[0] == b[0] for a, b in zip(h0, h1))
+    print(f"full size: worst relative difference of a step's decoder output over 150 steps {worst:.4f}; unforced, "
+          f"{same} / 128 best hypotheses identical over 150 tokens")
