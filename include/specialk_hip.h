@@ -64,8 +64,10 @@ int skhip_init(void);
  * run one workgroup per CU and size their tiles so that a launch fills whole rounds of the chip.  When another
  * kernel holds CUs for as long as they run — RCCL's all-reduce kernels during the backward pass of a data-parallel
  * step — a launch planned for all CUs needs a second, almost empty round.  n = the CUs to leave out of that
- * planning (0 = none, the default; SKHIP_RESERVE_CUS sets the start value).  Affects scheduling only, never
- * results.  Not thread-safe against concurrent GEMM calls.                                                    */
+ * planning (0 = none, the default; SKHIP_RESERVE_CUS sets the start value).  Tile shapes, K-split counts and the
+ * chunking of column sums and LayerNorm-gradient partials follow the planned CU count, so results with and without
+ * a reserve agree to fp32 summation order (bf16 outputs: to one rounding step), not bit for bit; with a fixed
+ * reserve every call is bit-reproducible.  Not thread-safe against concurrent GEMM calls.                      */
 int skhip_set_reserved_cus(int n);
 
 /* ---- GEMM ---------------------------------------------------------------------------

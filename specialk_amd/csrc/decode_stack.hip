@@ -21,8 +21,12 @@
 // then on, so every wave reaches the end of the kernel whatever happens), workgroup barrier, invalidation of the
 // CU's L1.  The members of a team have the same block index modulo 8, which the dispatcher places on ONE XCD:
 // they share an L2, so the exchange needs no L2 write-back or invalidation (agent-scope fences cost 20-80 us
-// per barrier here: 160 workgroups flushing eight L2s thirty-six times a step).  Should a dispatcher ever spread
-// a team over XCDs, its counter would not advance and the error word says so.  Members of a team are
+// per barrier here: 160 workgroups flushing eight L2s thirty-six times a step).  The exchange is only correct under
+// that placement (the counter's agent-scope atomics are served past the L2 and would advance all the same, while
+// the slices of a member on another XCD would be read stale), so the kernel VERIFIES it: every member ORs the bit
+// of the XCC it runs on (hardware register XCC_ID) into a word of its team before the first barrier, and the
+// team's leaders look at the word after it; more than one bit raises the error word (value 2) and the caller
+// must discard the step.  Members of a team are
 // 8 workgroups of one launch of at most one workgroup per CU (the host checks teams x 8 <= CUs), so all of
 // them are resident together.  The counters alternate between two sets by step parity: a launch zeroes the set
 // of the other parity, which nothing touches meanwhile.
@@ -52,7 +56,7 @@ struct StackArgs {
   const int32_t* cur_len; const uint8_t* row_pad; const uint8_t* pad_hist; const int32_t* hist;
   const uint8_t* src_key_pad;
   bf16_t* dec_out;
-  int32_t* flags;   // [2][MAX_TEAMS] team counters, then one error word
+  int32_t* flags;   // [2][MAX_TEAMS] team counters, one error word (index 2 MAX_TEAMS), [2][MAX_TEAMS] XCC masks from index 3 MAX_TEAMS
   bf16_t* att;      // [R32][512]
   float* zbuf;      // [R32][512]
   float* pbuf;      // [8][R32][512]
@@ -863,7 +867,16 @@ __global__ __launch_bounds__(NTHREADS) void decode_stack_kernel(StackArgs a) {
   ctx.err = a.flags + 2 * MAX_TEAMS;
   ctx.count = 0;
   ctx.dead = false;
-  if (m0 == 0 && tid_ == 0) a.flags[(a.parity ^ 1) * MAX_TEAMS + team] = 0;   // the next step's counter
+  int32_t* const xcc_mask = a.flags + (3 + a.parity) * MAX_TEAMS + team;
+  if (m0 == 0 && tid_ == 0) {   // the next step's counter and XCC mask
+    a.flags[(a.parity ^ 1) * MAX_TEAMS + team] = 0;
+    a.flags[(3 + (a.parity ^ 1)) * MAX_TEAMS + team] = 0;
+  }
+  if (tid_ == 0) {   // (the first barrier waits for this request like for every other one of the wave)
+    uint32_t xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
+    __hip_atomic_fetch_or(xcc_mask, 1 << xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
 
   // q | k | v of head m are 12 column tiles of 16: tile t = (which = t / 4, sub = t % 4); wave w takes tile w, and
   // waves 0..3 tile 8 + w as well
@@ -1251,6 +1264,12 @@ __global__ __launch_bounds__(NTHREADS) void decode_stack_kernel(StackArgs a) {
     STAMP();  // 16: after LN
   }
 #undef STAMP
+  // every member's bit has been in the team's XCC mask since the first barrier: exactly one bit, or the exchanges
+  // above read another L2's stale lines
+  if (tid_ == 0) {
+    const int mk = __hip_atomic_load(xcc_mask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (__popc(mk) != 1) __hip_atomic_store(ctx.err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   // the stack's output rows, columns 64 m .. 64 m + 63 by member m
   {
     IDS();

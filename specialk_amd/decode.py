@@ -17,6 +17,7 @@ penalty; step 1 only expands beam 0.
 """
 import os
 import time
+import warnings
 
 import numpy as np
 import torch
@@ -24,6 +25,10 @@ import torch
 from . import _lib as L
 from . import ops
 from .core import constants as Constants
+
+
+class _StackGaveUp(RuntimeError):
+    """The one-launch decoder stack set its error word: the batch's results are not to be used."""
 
 
 class BeamDecoder:
@@ -36,6 +41,8 @@ class BeamDecoder:
         # run the decoder stack of a step as ONE launch where the shape allows it (bf16, d_model 512, 8 heads of 64,
         # d_inner 2048, at most 32 x CUs / 8 beam rows); SK_DECODE_STACK=0: always op by op
         self.use_stack = os.environ.get("SK_DECODE_STACK", "1") != "0" if use_stack is None else bool(use_stack)
+        self.stack_fallbacks = 0       # batches searched again op by op after the stack kernel's error word was set
+        self.poke_stack_error = 0      # tests only: set the error word to this value after the steps
         # debugging aids (host-launched steps only): `trace` receives (decoder output, new_scores, prev, new_tok) of
         # every step; `forced` replaces the search's choice of step i by forced[i] = (new_scores, prev, new_tok)
         self.trace, self.forced = None, None
@@ -82,6 +89,18 @@ class BeamDecoder:
 
     @torch.no_grad()
     def run(self, src_seq, src_pos, n_best=1):
+        """Beam search of a batch (Translator.translate_batch, Translator.py:53-171).  The one-launch decoder stack
+        reports through an error word when its workgroups could not exchange their slices (a team not resident
+        together or not on one XCD): the batch is then searched again with one launch per operation, in this
+        process, and self.stack_fallbacks counts it."""
+        try:
+            return self._run(src_seq, src_pos, n_best, self.use_stack)
+        except _StackGaveUp as e:
+            self.stack_fallbacks = getattr(self, "stack_fallbacks", 0) + 1
+            warnings.warn(f"{e}; searching this batch again with one launch per operation")
+            return self._run(src_seq, src_pos, n_best, False)
+
+    def _run(self, src_seq, src_pos, n_best, use_stack):
         model, bm, Tmax = self.model, self.bm, self.max_len
         dec = model.decoder
         dt = dec.compute_dtype
@@ -176,8 +195,9 @@ class BeamDecoder:
             return y
 
         F = layers[0].pos_ffn.w_1.weight.shape[0]
-        stack = (self.use_stack and dt == torch.bfloat16 and (d, H, dk, dv, F) == (512, 8, 64, 64, 2048) and NL <= 8
-                 and R <= 32 * (torch.cuda.get_device_properties(dev).multi_processor_count // 8))
+        # (teams of 8 workgroups x 32 rows, at most 32 teams, all resident together at one workgroup per CU)
+        stack = (use_stack and dt == torch.bfloat16 and (d, H, dk, dv, F) == (512, 8, 64, 64, 2048) and NL <= 8
+                 and R <= 32 * min(32, torch.cuda.get_device_properties(dev).multi_processor_count // 8))
         if stack:
             f32 = lambda p: p.detach().float().contiguous()
 
@@ -302,10 +322,15 @@ class BeamDecoder:
         mark("steps")
         del graph
         self.last_steps = steps
-        if stack and int(stack_ws[4 * L.STACK_ERR_WORD:4 * L.STACK_ERR_WORD + 4].view(torch.int32).item()) != 0:
-            raise RuntimeError("skhip_decode_stack: a team member stopped waiting for its team; results are invalid")
         if was_training:
             model.train()
+        if stack:
+            if self.poke_stack_error:   # tests: as if a member had given up
+                stack_ws[4 * L.STACK_ERR_WORD:4 * L.STACK_ERR_WORD + 4].view(torch.int32).fill_(int(self.poke_stack_error))
+            err = int(stack_ws[4 * L.STACK_ERR_WORD:4 * L.STACK_ERR_WORD + 4].view(torch.int32).item())
+            if err != 0:
+                raise _StackGaveUp("skhip_decode_stack: " + ("a team's workgroups ran on more than one XCD" if err == 2 else
+                                                             "a team member stopped waiting for its team"))
 
         # hypotheses: walk the back-pointers on the host (Beam.get_hypothesis, Beam.py:103-110), all sentences and
         # ranks in step: one gather per position instead of one Python iteration per token

@@ -185,6 +185,7 @@ def refresh_derived():
     update, whose kernel changes the parameters without touching torch's version counters)."""
     global _derived_tables, _weights_epoch
     _weights_epoch += 1
+    _pending_dres.clear()   # an optimiser update ends the step: nothing of its backward pass is still on its way
     if not _derived:
         return
     if _derived_tables is None:
@@ -208,7 +209,10 @@ def _bias_grad(dy, T, N):
     return L.colsum(dy, T, N, N)
 
 
-_pending_dres = {}  # data_ptr of a gradient whose residual part AddLNFn.backward handed on -> not yet picked up
+# data_ptr of a gradient whose residual part AddLNFn.backward handed on -> not yet picked up.  Process-wide, so it is
+# emptied wherever a step begins or ends (batched_weight_grads entry and exit, the optimiser's refresh_derived): a
+# backward pass that was aborted between a hand-over and its pick-up must not fail the next, unrelated one.
+_pending_dres = {}
 
 
 def _residual_grad(dy):
@@ -342,11 +346,13 @@ def batched_weight_grads(on_ready=None, flush_tiles=256):
     if _wgrad_batch is not None:
         raise RuntimeError("batched_weight_grads() does not nest")
     _wgrad_batch = _WeightGradBatch(on_ready, flush_tiles)
+    _pending_dres.clear()
     try:
         yield
         _flush_weight_grads()
     finally:
         _wgrad_batch = None
+        _pending_dres.clear()
 
 
 def _reducer():
@@ -370,6 +376,9 @@ def _grad_target(p, fixups, reducer=None):
     """(tensor the launch writes, accumulate?) for the gradient of p: p.grad itself when it can be written in
     place, the reducer's bucket slice or a fresh tensor that becomes p.grad when there is none, else a temporary
     that is added afterwards."""
+    late = reducer.late_target(p) if reducer is not None and hasattr(reducer, "late_target") else None
+    if late is not None:  # the bucket that holds this gradient has already started its all-reduce
+        return late, False
     g = p.grad
     if g is None:
         view, acc = reducer.claim(p) if reducer is not None else (None, False)
@@ -427,6 +436,11 @@ def _weight_grad(dy, x, W, T, needed=True, bias=None):
         if needed:
             dW = L.gemm(L.GEMM_TN, dy, x, n, d_in, T, dy.stride(0), x.stride(0), out_dtype=torch.float32).view(W.shape)
         return dW, (None if bias is None else L.colsum(dy, T, n, dy.stride(0)))
+    r = _reducer()
+    if r is not None and hasattr(r, "direct"):  # counted when the grouped launch reports them, not by autograd's hooks
+        r.direct(W)
+        if bias is not None:
+            r.direct(bias)
     if W.data_ptr() in b.seen:  # two products into one gradient must not share a launch
         _flush_weight_grads()
     b.seen.add(W.data_ptr())

@@ -23,6 +23,14 @@ NOT zeroed (392 MB per step for the base model): the first producer of a gradien
     one-dimensional parameters in a 6+6 Transformer, ~5 us each).  When a bucket is complete those tensors are
     copied into it by one multi-tensor copy, after which .grad is the bucket view again.
   * A parameter that got no gradient in a step has its slice zeroed in finish(), before the bucket is reduced.
+  * A producer that writes a gradient in place announces the parameter with direct(p) when its backward runs and
+    reports it with mark_ready([p]) once the gradient is written; such a parameter must not reach .grad through
+    autograd in the same step as well.
+  * Readiness is counted per parameter: a matrix that several layers share is reported by mark_ready once per
+    grouped launch that wrote a part of its gradient, and its bucket must wait for the last of them.  How many
+    reports a parameter makes per step is learned (the largest count seen so far, 1 to begin with); in the step
+    that first shows a further report the bucket may already be on its way, and the late part is then written to a
+    tensor of its own (late_target), reduced by itself in finish() and added to the bucket's sum.
 """
 import os
 
@@ -64,7 +72,11 @@ class GradBucketReducer:
                         and dist.get_backend(process_group) != "nccl")
         self._bucket_of = {p.data_ptr(): bi for bi, (_, plist) in enumerate(self.buckets) for p in plist}
         self._views, self._claimed = {}, set()
+        self._expected, self._reports = {}, {}   # id(p) -> mark_ready reports per step (learned) / so far this step
+        self._launched, self._late = set(), []   # buckets whose all-reduce has started / [(param, late gradient part)]
+        self._direct = set()                     # id(p) of parameters announced with direct() this step
         self.gathered_matrix_bytes = 0  # diagnostics: matrix gradients that took the copy instead of a direct write
+        self.late_parts = 0             # diagnostics: gradient parts produced after their bucket had left
         # SK_DP_RESERVE_CUS=n: from a step's first all-reduce until finish() the large-tile GEMMs plan their rounds
         # for n CUs fewer (skhip_set_reserved_cus): RCCL's kernels hold CUs meanwhile, and a launch planned for all
         # of them then needs an extra, almost empty round.  0 (default): off — how many CUs RCCL takes has to be
@@ -107,15 +119,29 @@ class GradBucketReducer:
                     p.grad = flat[off:off + n].view(p.shape)
                 off += n
 
+    def _count(self, bi):
+        """One more parameter of bucket bi has its gradient: the last one starts the bucket's all-reduce."""
+        self._pending[bi] -= 1
+        if self._pending[bi] == 0:
+            flat = self.buckets[bi][0]
+            self._gather_late(bi)
+            self._reserve(True)
+            self._launched.add(bi)
+            self._handles.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
     def _make_hook(self, bi):
-        def hook(_p):
-            self._pending[bi] -= 1
-            if self._pending[bi] == 0:
-                flat = self.buckets[bi][0]
-                self._gather_late(bi)
-                self._reserve(True)
-                self._handles.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        def hook(p):
+            # (autograd runs a parameter's accumulation node, and with it this hook, even when the producer handed it
+            # no gradient: a parameter announced with direct() counts when mark_ready reports it, not here)
+            if id(p) not in self._direct:
+                self._count(bi)
         return hook
+
+    def direct(self, p):
+        """Announce, before the backward pass reaches the accumulation node of p, that this step's gradient of p is
+        written by its producer in place and reported with mark_ready (ops.batched_weight_grads does so when it
+        queues a product)."""
+        self._direct.add(id(p))
 
     def _reserve(self, on):
         if self.reserve_cus > 0 and on != self._reserved:
@@ -136,18 +162,35 @@ class GradBucketReducer:
         the first claim of a step must overwrite the slice (it still holds the previous step's sum), later ones
         — further uses of a shared matrix — add to it.  (None, False) when there is nothing to write into."""
         view = self.bucket_view(p)
-        if view is None:
+        if view is None or self._bucket_of[p.data_ptr()] in self._launched:
             return None, False
         first = id(p) not in self._claimed
         self._claimed.add(id(p))
         return view, not first
 
+    def late_target(self, p):
+        """A tensor of its own for a part of the gradient of p that is produced after the bucket of p has started
+        its all-reduce (a shared matrix's further use, in the first step that shows it), or None when the bucket
+        can still be written.  finish() reduces the tensor and adds it to the bucket's sum."""
+        if not self.active or self._staged or self._bucket_of.get(p.data_ptr()) not in self._launched:
+            return None
+        t = torch.empty(p.shape, dtype=torch.float32, device=p.device)
+        self.late_parts += 1
+        self._late.append((p, t))
+        return t
+
     def mark_ready(self, params):
         """Cue for gradients that were written into the bucket views directly instead of being
-        accumulated by autograd (ops.batched_weight_grads): counts them like the hooks do."""
+        accumulated by autograd (ops.batched_weight_grads).  A parameter counts towards its bucket when the last
+        of its expected reports of the step has come in (see the module docstring)."""
         if self.active and not self._staged:
             for p in params:
-                self._make_hook(self._bucket_of[p.data_ptr()])(p)
+                k = self._reports[id(p)] = self._reports.get(id(p), 0) + 1
+                want = self._expected.get(id(p), 1)
+                if k == want:
+                    self._count(self._bucket_of[p.data_ptr()])
+                elif k > want:   # a further use, seen for the first time: expected from the next step on
+                    self._expected[id(p)] = k
 
     def zero_grad(self):
         """Start a step.  Exchanging gradients: every .grad is dropped and nothing is zeroed (see the module
@@ -159,6 +202,7 @@ class GradBucketReducer:
             self._pending[bi] = len(plist)
             self._reattach(flat, plist)  # also repairs views a foreign zero_grad(set_to_none=True) detached
         self._claimed = set()
+        self._reports, self._launched, self._late, self._direct = {}, set(), [], set()
         self._handles = []
 
     def _reattach(self, flat, plist):
@@ -199,6 +243,10 @@ class GradBucketReducer:
                     self._pending[bi] = 0
             for h in self._handles:
                 h.wait()
+            for p, t in self._late:   # (same order on every rank: the order of the backward pass)
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+                self._views[id(p)].add_(t)
+            self._late = []
             self._reserve(False)
         if self.active:  # every .grad is the bucket view again (parameters without a gradient read as zero)
             for flat, plist in self.buckets:

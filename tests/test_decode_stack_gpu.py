@@ -294,3 +294,53 @@ def test_full_size_decode_stack_against_op_by_op():
     same = sum(a[0] == b[0] for a, b in zip(h0, h1))
     print(f"full size: worst relative difference of a step's decoder output over 150 steps {worst:.4f}; unforced, "
           f"{same} / 128 best hypotheses identical over 150 tokens")
+
+
+def test_error_word_sends_the_batch_to_the_op_by_op_path():
+    """A set error word (a member gave up, or a team found itself on two XCDs) must not reach the caller as an
+    exception or as wrong tokens: the batch is searched again with one launch per operation."""
+    import warnings
+    from specialk_amd.decode import BeamDecoder
+    model = build(2)
+    src, pos = batch(6, 5, 12, 1000, 3)
+    ref_dec = BeamDecoder(model, 4, 12, use_stack=False)
+    ref_hyp, ref_scores = ref_dec.run(src, pos, n_best=2)
+    for code in (1, 2):
+        dec = BeamDecoder(model, 4, 12, use_stack=True)
+        dec.poke_stack_error = code
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            hyp, scores = dec.run(src, pos, n_best=2)
+        assert dec.stack_fallbacks == 1 and not dec.used_stack
+        assert any("skhip_decode_stack" in str(x.message) for x in w)
+        assert hyp == ref_hyp
+        for a, b in zip(scores, ref_scores):
+            assert torch.equal(a, b)
+
+
+def test_teams_report_one_xcd_each():
+    """After a launch every team's XCC mask has exactly one bit (its 8 workgroups share an L2) and the error word is 0."""
+    from specialk_amd import _lib as L
+    from specialk_amd.decode import BeamDecoder
+    model = build(1)
+    src, pos = batch(40, 5, 9, 1000, 4)   # 200 rows: several teams
+    dec = BeamDecoder(model, 5, 4, use_stack=True)
+    seen = {}
+    real = L.decode_stack
+
+    def spy(*a, **k):
+        seen["ws"] = a[12]
+        return real(*a, **k)
+
+    L.decode_stack = spy
+    try:
+        dec.run(src, pos)
+    finally:
+        L.decode_stack = real
+    assert dec.used_stack and dec.stack_fallbacks == 0
+    words = seen["ws"][:1024].view(torch.int32).cpu()
+    assert int(words[L.STACK_ERR_WORD]) == 0
+    masks = words[96:160].view(2, 32)
+    used = masks[masks != 0]
+    assert used.numel() >= 2
+    assert all(bin(int(m)).count("1") == 1 for m in used), masks

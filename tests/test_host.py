@@ -139,6 +139,7 @@ def _dp_worker(rank, world, port, out):
         @staticmethod
         def backward(ctx, dy):
             inp, W = ctx.saved_tensors
+            red.direct(W)
             view, acc = red.claim(W)
             assert not acc and W.grad is None
             view.copy_(dy.t() @ inp)
@@ -183,6 +184,89 @@ def test_grad_bucket_reducer_sums_over_two_ranks(tmp_path):
             torch.testing.assert_close(g, p.grad, rtol=1e-5, atol=1e-6)
         assert torch.count_nonzero(got["grads"][it][-1]) == 0     # the unused parameter stays zero
     assert got["tot"].tolist() == [3.0, 4.0, 1.0]
+
+
+def _dp_shared_worker(rank, world, port, out):
+    """A matrix used by two layers, each use writing its part of the gradient into the bucket and reporting it with
+    a mark_ready of its own (two grouped launches of ops.batched_weight_grads)."""
+    import torch.distributed as dist
+    from specialk_amd.parallel import GradBucketReducer
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(3)
+    W = torch.nn.Parameter(torch.randn(16, 16) * 0.3)
+    first, last = torch.nn.Linear(6, 16), torch.nn.Linear(16, 3)
+    params = list(first.parameters()) + [W] + list(last.parameters())
+    red = GradBucketReducer(params, bucket_mb=1e-3)   # W (256 floats) fills a bucket of its own
+    assert len(red.buckets) >= 3
+    events = []
+
+    class SharedUse(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, inp, W):
+            ctx.save_for_backward(inp, W)
+            return inp @ W.t()
+
+        @staticmethod
+        def backward(ctx, dy):
+            inp, W = ctx.saved_tensors
+            g = dy.t() @ inp
+            red.direct(W)
+            late = red.late_target(W)
+            if late is not None:
+                late.copy_(g)
+                events.append("late")
+            else:
+                view, acc = red.claim(W)
+                if acc:
+                    view.add_(g)
+                else:
+                    view.copy_(g)
+                    W.grad = view
+                events.append("acc" if acc else "first")
+            red.mark_ready([W])
+            return dy @ W, None
+
+    x = torch.randn(8, 6, generator=torch.Generator().manual_seed(1))
+    y = torch.randn(8, 3, generator=torch.Generator().manual_seed(2))
+    per = 8 // world
+    res = []
+    for it in range(3):
+        red.zero_grad()
+        xs, ys = x[rank * per:(rank + 1) * per], y[rank * per:(rank + 1) * per]
+        h = torch.tanh(first(xs))
+        h = torch.tanh(SharedUse.apply(h, W))
+        h = torch.tanh(SharedUse.apply(h, W))
+        (((last(h) - ys) ** 2).sum() * (it + 1)).backward()
+        red.finish()
+        res.append([p.grad.clone() for p in params])
+    if rank == 0:
+        torch.save({"grads": res, "events": events}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_reducer_waits_for_every_use_of_a_shared_matrix(tmp_path):
+    out = str(tmp_path / "dp.pt")
+    mp.spawn(_dp_shared_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = torch.load(out)
+    # step 1 learns about the second use after the bucket has left (late tensor, reduced by itself);
+    # from step 2 on the bucket waits for both reports
+    assert got["events"] == ["first", "late", "first", "acc", "first", "acc"]
+    torch.manual_seed(3)
+    W = torch.nn.Parameter(torch.randn(16, 16) * 0.3)
+    first, last = torch.nn.Linear(6, 16), torch.nn.Linear(16, 3)
+    params = list(first.parameters()) + [W] + list(last.parameters())
+    x = torch.randn(8, 6, generator=torch.Generator().manual_seed(1))
+    y = torch.randn(8, 3, generator=torch.Generator().manual_seed(2))
+    for it in range(3):
+        for p in params:
+            p.grad = None
+        h = torch.tanh(first(x))
+        h = torch.tanh(torch.tanh(h @ W.t()) @ W.t())
+        (((last(h) - y) ** 2).sum() * (it + 1)).backward()
+        for g, p in zip(got["grads"][it], params):
+            torch.testing.assert_close(g, p.grad, rtol=1e-5, atol=1e-6)
 
 
 def test_single_process_reducer_is_a_no_op_wrapper():

@@ -69,7 +69,7 @@ def _worker(rank, world, port, out, packed, bf16=False, backend="gloo", tied=Fal
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
     if rank == 0:
         res = {"grads": {k: p.grad.cpu() for k, p in m.named_parameters() if p.grad is not None}, "stats": tot.cpu(),
-               "gathered_matrix_bytes": red.gathered_matrix_bytes}
+               "gathered_matrix_bytes": red.gathered_matrix_bytes, "late_parts": red.late_parts}
         if bf16:  # reference for the bf16 run: the same arithmetic on the whole batch in one process, through autograd
             m2 = load_sd(build_tiny(g, tied), split_prefixed(g, "w:")).eval().set_compute_dtype(torch.bfloat16)
             logits, gold = m2.forward_packed(*batch) if packed else (None, None)
@@ -132,6 +132,7 @@ def test_one_rank_rccl_rehearsal(tmp_path, bf16, tied):
     got = torch.load(out)
     if bf16:
         assert got["gathered_matrix_bytes"] == 0
+        assert got["late_parts"] == 0   # no bucket left before the last of its gradients was written
         for k, ref in got["ref"].items():
             a, b = got["grads"][k].double(), ref.double()
             assert float((a - b).norm()) <= 3e-2 * float(b.norm()) + 1e-6, k
@@ -181,3 +182,21 @@ def test_translate_shards_sentences_over_ranks(tmp_path, monkeypatch):
     one, many = (tmp_path / "one.txt").read_text(), (tmp_path / "many.txt").read_text()
     assert len(one.split("\n")) == 8 and one == many
     assert not list(tmp_path.glob("many.txt.rank*"))
+
+
+def test_bench_launches_its_own_ranks():
+    """`bench.py --gpus 2` started as a plain process must come back with a line measured by two ranks (it starts them
+    itself).  Rehearsed on one card: both ranks on device 0, gloo transport."""
+    import json
+    import subprocess
+    env = dict(os.environ, SK_BENCH_DEVICE="0", SK_BENCH_BACKEND="gloo")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--no-decode", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["ranks_seen"] == 2 and len(res["ms_per_step_by_rank"]) == 2
+    assert res["steps"] == 3 and res["value"] > 0
