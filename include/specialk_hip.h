@@ -245,6 +245,15 @@ int skhip_embed_bwd(const int64_t* seq, const void* dout, float* dword_emb, int6
 int skhip_pack_plan(const int64_t* seq, int B, int L, int trim, int64_t pad_id, int32_t* lens,
                     int32_t* off, int64_t* idx, int64_t* facts, void* stream);
 
+/* skhip_pack_plan for up to 4 batches in one pair of launches (a step's source and target batch), with the range
+ * check that nn.Embedding makes on the host (lib/transformer/Models.py:117-118,181-183: an id or position outside its
+ * table raises IndexError there).  desc: HOST table of 12 int64 per batch: {seq address, pos address or 0, row stride
+ * of seq, row stride of pos (elements), B, L, trim, n_vocab (<= 0: ids not checked), n_pos, lens address, off
+ * address, idx address}; lens / off / idx as in skhip_pack_plan.  B, L >= 1.
+ * facts [n][6] (device) = {right-padded, min_b(#non-PAD - trim), max_b lens, n rows, every id in [0, n_vocab),
+ * every position in [0, n_pos)}.                                                                              */
+int skhip_pack_plans(const int64_t* desc, int n, int64_t pad_id, int64_t* facts, void* stream);
+
 /* Batch collation on the device (collate_fn, core/dataset.py:21-46): the B sentences of a batch arrive as one
  * flat id array (sentence b = flat[off[b] .. off[b+1]-1], off[B+1] int64) and are written right-padded with
  * pad_id into seq [B][L] (L >= the longest sentence; longer sentences are cut at L), with pos [B][L] =

@@ -21,7 +21,7 @@ LIB_PATH = os.environ.get("SKHIP_LIB") or os.path.join(_HERE, "libspecialk_hip.s
 EXPORTS = [
     "skhip_version", "skhip_last_error", "skhip_init", "skhip_gemm", "skhip_gemm_grouped_tn", "skhip_colsum", "skhip_colsum_noalloc", "skhip_attn_fwd",
     "skhip_attn_bwd", "skhip_attn_varlen_fwd", "skhip_attn_varlen_bwd", "skhip_add_ln_fwd", "skhip_add_ln_bwd_ws_floats", "skhip_add_ln_bwd", "skhip_embed_fwd",
-    "skhip_embed_bwd", "skhip_pack_plan", "skhip_xent_fwd_bwd", "skhip_adam_multi", "skhip_cast_multi", "skhip_cast2d_multi", "skhip_convert",
+    "skhip_embed_bwd", "skhip_pack_plan", "skhip_pack_plans", "skhip_xent_fwd_bwd", "skhip_adam_multi", "skhip_cast_multi", "skhip_cast2d_multi", "skhip_convert",
     "skhip_decode_attn", "skhip_beam_topk_ws_bytes", "skhip_beam_topk", "skhip_beam_update", "skhip_gather_rows",
     "skhip_decode_stack_ws_bytes", "skhip_decode_stack", "skhip_beam_topk_stats", "skhip_beam_step",
     "skhip_softmax_rows", "skhip_conv_windows", "skhip_cnn_head", "skhip_collate", "skhip_set_reserved_cus",
@@ -50,6 +50,7 @@ def load():
     lib.skhip_beam_topk_ws_bytes.restype = c_i64
     lib.skhip_beam_topk_ws_bytes.argtypes = [c_int, c_int, c_i64]
     lib.skhip_pack_plan.argtypes = [c_p, c_int, c_int, c_int, c_i64, c_p, c_p, c_p, c_p, c_p]
+    lib.skhip_pack_plans.argtypes = [c_p, c_int, c_i64, c_p, c_p]
     lib.skhip_collate.argtypes = [c_p, c_p, c_int, c_int, c_i64, c_p, c_p, c_p]
     lib.skhip_gemm_grouped_tn.argtypes = [ctypes.POINTER(c_i64), c_int, c_p, c_i64, c_p]
     lib.skhip_gemm.argtypes = [c_int, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_f32,
@@ -356,6 +357,53 @@ def pack_plan(seq, trim, pad_id):
     _check(lib.skhip_pack_plan(_ptr(seq), B, L, int(trim), int(pad_id), _ptr(lens), _ptr(off), _ptr(idx), _ptr(facts),
                                _stream()), "skhip_pack_plan")
     return lens, off, idx, facts
+
+
+PACK_FACTS = 6
+
+
+def pack_plans(items, pad_id):
+    """Row bookkeeping of several right-padded id batches in one pair of launches (skhip_pack_plans).
+    items: [(seq (B, L) int64, pos (B, L) int64 or None, trim, n_vocab (0: ids not checked), n_pos)], rows may be
+    strided.  -> ([(lens, off, idx)], facts int64 (len(items), 6) on the device)."""
+    lib = load()
+    dev = items[0][0].device
+    empty = [it[0].numel() == 0 for it in items]
+    if any(empty):  # batches without rows or columns: nothing to launch for them
+        full = [it for it, e in zip(items, empty) if not e]
+        sub_outs, sub_facts = pack_plans(full, pad_id) if full else ([], None)
+        facts = torch.tensor([[1, 0x7fffffff, 0, 0, 1, 1]] * len(items), dtype=torch.int64, device=dev)
+        outs, j = [], 0
+        for k, (it, e) in enumerate(zip(items, empty)):
+            if e:
+                B = it[0].shape[0]
+                outs.append((torch.zeros(B, dtype=torch.int32, device=dev), torch.zeros(B + 1, dtype=torch.int32, device=dev),
+                             torch.zeros(0, dtype=torch.int64, device=dev)))
+            else:
+                outs.append(sub_outs[j])
+                facts[k] = sub_facts[j]
+                j += 1
+        return outs, facts
+    table = (ctypes.c_int64 * (12 * len(items)))()
+    outs, keep = [], []
+    for k, (seq, pos, trim, n_vocab, n_pos) in enumerate(items):
+        B, Ln = seq.shape
+        if seq.stride(1) != 1:
+            seq = seq.contiguous()
+        if pos is not None and pos.stride(1) != 1:
+            pos = pos.contiguous()
+        assert seq.dtype == torch.int64 and (pos is None or (pos.dtype == torch.int64 and pos.shape == seq.shape))
+        lens = torch.empty(B, dtype=torch.int32, device=dev)
+        off = torch.empty(B + 1, dtype=torch.int32, device=dev)
+        idx = torch.empty(B * Ln, dtype=torch.int64, device=dev)
+        keep.append((seq, pos))
+        outs.append((lens, off, idx))
+        table[12 * k:12 * k + 12] = [seq.data_ptr(), 0 if pos is None else pos.data_ptr(), seq.stride(0),
+                                     0 if pos is None else pos.stride(0), B, Ln, int(trim), int(n_vocab), int(n_pos),
+                                     lens.data_ptr(), off.data_ptr(), idx.data_ptr()]
+    facts = torch.empty((len(items), PACK_FACTS), dtype=torch.int64, device=dev)
+    _check(lib.skhip_pack_plans(table, len(items), int(pad_id), _ptr(facts), _stream()), "skhip_pack_plans")
+    return outs, facts
 
 
 def collate(flat, off, B, L, pad_id):

@@ -86,31 +86,29 @@ class PendingPlans:
             self.event.synchronize()
             facts = self.facts_host.tolist()
             plans = []
-            for k, (seq, (off, idx)) in enumerate(zip(self.seqs, self.parts)):
-                ok, lo, mx, n = facts[4 * k:4 * k + 4]
+            for seq, (off, idx), (ok, lo, mx, n, ids_ok, pos_ok) in zip(self.seqs, self.parts, facts):
                 if not ok or lo < 0:
                     raise ValueError("packed execution needs right-padded batches whose sentences hold at least `trim` tokens")
+                if not (ids_ok and pos_ok):
+                    raise IndexError("token id or position outside its embedding table")
                 plans.append(PackPlan(off, idx, seq.shape[0], seq.shape[1], mx, n))
-            if self.checked and not all(facts[4 * len(self.seqs):]):
-                raise IndexError("token id or position outside its embedding table")
             self._plans = plans
         return self._plans
 
 
 def plan_packing_async(seqs, trims, check=None):
     """Starts the packing plans of right-padded id batches `seqs` (each (B, L) on the GPU), keeping the first
-    len_b - trim tokens of every sentence.  Lengths, offsets and row indices are computed on the device (two small
-    launches per batch); what the host must know (row counts, longest sentence, whether the batches really are
-    right-padded and, if `check` is given, whether ids / positions fit their tables) travels in ONE device -> host
-    copy into pinned memory that is not waited for here."""
-    parts, facts = [], []
-    for seq, trim in zip(seqs, trims):
-        _, off, idx, f = _L.pack_plan(seq, trim, Constants.PAD)
-        parts.append((off, idx))
-        facts.append(f)
-    if check is not None:
-        facts.append(torch.stack([(t.max() < limit).to(torch.int64) * (t.min() >= 0).to(torch.int64) for t, limit in check]))
-    facts = torch.cat(facts)
+    len_b - trim tokens of every sentence.  Lengths, offsets and row indices are computed on the device (two
+    launches for all batches together); what the host must know (row counts, longest sentence, whether the batches
+    really are right-padded and, if `check` is given — per batch (positions, vocabulary size, position-table rows) —
+    whether ids / positions fit their tables) travels in ONE device -> host copy into pinned memory that is not
+    waited for here."""
+    items = []
+    for k, (seq, trim) in enumerate(zip(seqs, trims)):
+        pos, n_vocab, n_pos = check[k] if check is not None else (None, 0, 0)
+        items.append((seq, pos, trim, n_vocab, n_pos))
+    outs, facts = _L.pack_plans(items, Constants.PAD)
+    parts = [(off, idx) for _, off, idx in outs]
     host = torch.empty(facts.shape, dtype=facts.dtype, pin_memory=True)
     host.copy_(facts, non_blocking=True)
     event = torch.cuda.Event()
@@ -281,8 +279,8 @@ class Transformer(nn.Module):
         check = None
         if self.encoder.check_ids:
             enc, dec = self.encoder, self.decoder
-            check = [(src_seq, enc.src_word_emb.num_embeddings), (src_pos, enc.position_enc.num_embeddings),
-                     (tgt_seq, dec.tgt_word_emb.num_embeddings), (tgt_pos, dec.position_enc.num_embeddings)]
+            check = [(src_pos, enc.src_word_emb.num_embeddings, enc.position_enc.num_embeddings),
+                     (tgt_pos, dec.tgt_word_emb.num_embeddings, dec.position_enc.num_embeddings)]
         return plan_packing_async([src_seq, tgt_seq], [0, 1], check)
 
     def forward_packed(self, src_seq, src_pos, tgt_seq, tgt_pos, plans=None):

@@ -163,8 +163,8 @@ def _style_batch(self, class_input, class_model, batch, smooth, want_logits=Fals
             check = None
             if m.encoder.check_ids:  # ids / positions outside their tables must raise, not reach a kernel
                 enc, dec = m.encoder, m.decoder
-                check = [(src_seq, enc.src_word_emb.num_embeddings), (src_pos, enc.position_enc.num_embeddings),
-                         (tgt_in, dec.tgt_word_emb.num_embeddings), (tgt_pos_in, dec.position_enc.num_embeddings)]
+                check = [(src_pos, enc.src_word_emb.num_embeddings, enc.position_enc.num_embeddings),
+                         (tgt_pos_in, dec.tgt_word_emb.num_embeddings, dec.position_enc.num_embeddings)]
             src_plan, tgt_plan = plan_packing([src_seq, tgt_in], [0, 0], check)
             with torch.no_grad():
                 enc_packed = m.encoder.forward_packed(src_seq, src_pos, src_plan)

@@ -619,6 +619,44 @@ def test_pack_plan(L):
     assert L.pack_plan(short.to(DEV), 2, 0)[3].cpu().tolist()[:2] == [1, -1]
 
 
+def test_pack_plans_matches_pack_plan_and_checks_ranges(L):
+    """Several batches in one call: the same lengths / offsets / indices / facts as skhip_pack_plan per batch (rows
+    longer than a wave, more sentences than the block has waves x 4, strided rows), and the two range flags."""
+    g = torch.Generator().manual_seed(13)
+
+    def make(B, Lmax, lo=1):
+        lens = torch.randint(lo, Lmax + 1, (B,), generator=g)
+        seq = torch.zeros(B, Lmax, dtype=torch.long)
+        for b in range(B):
+            seq[b, :lens[b]] = torch.randint(1, 50, (int(lens[b]),), generator=g)
+        pos = (torch.arange(Lmax)[None, :] + 1) * (seq != 0)
+        return seq.to(DEV), pos.to(DEV)
+
+    a, b, c = make(640, 53, 2), make(7, 150), make(2500, 6, 2)
+    wide = torch.zeros(640, 60, dtype=torch.long, device=DEV)
+    wide[:, :53] = a[0]
+    items = [(wide[:, :53], a[1], 1, 50, 54), (b[0], None, 0, 0, 0), (c[0], c[1], 1, 50, 7)]
+    outs, facts = L.pack_plans(items, 0)
+    facts = facts.cpu().tolist()
+    for (seq, pos, trim, nv, npos), (ln, off, idx), f in zip(items, outs, facts):
+        ln1, off1, idx1, f1 = L.pack_plan(seq.contiguous(), trim, 0)
+        n = int(off1[-1])
+        assert torch.equal(ln, ln1) and torch.equal(off, off1) and torch.equal(idx[:n], idx1[:n])
+        assert f[:4] == f1.cpu().tolist() and f[4:] == [1, 1]
+    # an id equal to the vocabulary size, a negative id, a position equal to the table size: flagged, each by itself
+    for which, (r, cidx, val) in {"id": (3, 1, 50), "neg": (600, 0, -1), "pos": (77, 2, 54)}.items():
+        seq, pos = a[0].clone(), a[1].clone()
+        (pos if which == "pos" else seq)[r, cidx] = val
+        _, f = L.pack_plans([(seq, pos, 1, 50, 54)], 0)
+        assert f.cpu().tolist()[0][4:] == ([1, 0] if which == "pos" else [0, 1]), which
+    # not right-padded; a sentence shorter than the trim; an empty batch beside a full one
+    bad = torch.tensor([[5, 0, 6, 0], [7, 8, 0, 0]], device=DEV)
+    short = torch.tensor([[5, 0, 0], [7, 8, 9]], device=DEV)
+    outs, f = L.pack_plans([(bad, None, 0, 0, 0), (short, None, 2, 0, 0), (torch.zeros(0, 5, dtype=torch.long, device=DEV), None, 0, 0, 0)], 0)
+    f = f.cpu().tolist()
+    assert f[0][0] == 0 and f[1][:2] == [1, -1] and f[2][:4] == [1, 0x7fffffff, 0, 0]
+
+
 # ------------------------------------------------------------------------------ decode
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_decode_attn(L, dtype):

@@ -1,4 +1,4 @@
-"""Per-shape table of the GEMM launches of one benchmark training step: every skhip_gemm call is
+"""Per-shape table of the GEMM launches of one benchmark training step: every skhip_gemm / skhip_rowpanel_gemm[_ln] call is
 bracketed by events on the launch stream; rows are grouped by (layout, M, N, K, epilogue).
 Usage: python tools/gemm_shapes.py [cfg2] [steps]"""
 import collections, os, sys
@@ -33,7 +33,18 @@ def timed_g(problems):
     e0.record(); orig_g(problems); e1.record()
     fl = sum(2.0 * M * N * K for _, _, _, M, N, K, *_ in problems)
     recs.append((("grp", len(problems), int(fl / 1e9), 0, 0, False), e0, e1))
-L.gemm, L.gemm_grouped_tn = timed, timed_g
+orig_p, orig_pl = L.rowpanel_gemm, L.rowpanel_gemm_ln
+def timed_p(a, w_fm, N, *args, **kw):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); out = orig_p(a, w_fm, N, *args, **kw); e1.record()
+    recs.append((("panel", a.shape[0], N, 512, kw.get("epilogue", 0), False), e0, e1))
+    return out
+def timed_pl(a, *args, **kw):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); out = orig_pl(a, *args, **kw); e1.record()
+    recs.append((("pan+LN", a.shape[0], 512, 512, 0, False), e0, e1))
+    return out
+L.gemm, L.gemm_grouped_tn, L.rowpanel_gemm, L.rowpanel_gemm_ln = timed, timed_g, timed_p, timed_pl
 for _ in range(steps):
     bench.train_step(m, opt, batch, None)
 torch.cuda.synchronize()
