@@ -64,47 +64,86 @@ __global__ __launch_bounds__(256) void cast_multi_kernel(const uint64_t* __restr
 }
 
 // Entry t: fp32 matrix src [R][C] (contiguous) -> dst, row stride ld, as bf16 or fp32, either as it
-// is (dst[r][c]) or transposed (dst[c][r]).  32x32 tiles through LDS so both sides stay coalesced.
+// is (dst[r][c]) or transposed (dst[c][r]).  64 x 64 tiles through LDS: 16-byte loads along the source rows, and for
+// bf16 destinations 16-byte stores along the destination rows (eight lanes a 128-byte line) or, fragment-major,
+// whole 1 KB fragments per wave and instruction.  fp32 or unaligned destinations are written element by element.
 __global__ __launch_bounds__(256) void cast2d_multi_kernel(const uint64_t* __restrict__ sp, const uint64_t* __restrict__ dp,
                                                            const int64_t* __restrict__ meta) {
-  __shared__ float tile[32][33];
+  __shared__ float tile[64][65];
   const int t = blockIdx.y;
   const int64_t R = meta[4 * t], C = meta[4 * t + 1], ld = meta[4 * t + 2], flags = meta[4 * t + 3];
   const bool transpose = flags & 1, dst_f32 = flags & 2;
-  const int fm_tiles = (int)((flags >> 2) & 3) * 2;  // 0: row-major destination, else fragment-major with 2 / 4 tiles per group
+  const int TT = (int)((flags >> 2) & 3) * 2;  // 0: row-major destination, else fragment-major with 2 / 4 tiles per group
   const float* s = (const float*)sp[t];
-  const int64_t tr = (R + 31) / 32, tc = (C + 31) / 32;
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int64_t nrow = transpose ? C : R, ncol = transpose ? R : C;   // the destination's shape
+  const int64_t tr = (R + 63) / 64, tc = (C + 63) / 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool src_vec = (C & 3) == 0 && ((uintptr_t)s & 15) == 0;
+  const bool dst_vec = !dst_f32 && (TT || ((ld & 7) == 0 && (dp[t] & 15) == 0));
   for (int64_t id = blockIdx.x; id < tr * tc; id += gridDim.x) {  // block-uniform trip count
-    const int64_t r0 = (id / tc) * 32, c0 = (id % tc) * 32;
+    const int64_t r0 = (id / tc) * 64, c0 = (id % tc) * 64;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int64_t r = r0 + ty + 8 * i, c = c0 + tx;
-      tile[ty + 8 * i][tx] = (r < R && c < C) ? s[r * C + c] : 0.f;
+      const int rr = (tid >> 4) + 16 * i, cc = (tid & 15) * 4;
+      const int64_t r = r0 + rr, c = c0 + cc;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (r < R) {
+        if (src_vec && c + 4 <= C) v = *(const float4*)(s + r * C + c);
+        else {
+          if (c < C) v.x = s[r * C + c];
+          if (c + 1 < C) v.y = s[r * C + c + 1];
+          if (c + 2 < C) v.z = s[r * C + c + 2];
+          if (c + 3 < C) v.w = s[r * C + c + 3];
+        }
+      }
+      tile[rr][cc] = v.x; tile[rr][cc + 1] = v.y; tile[rr][cc + 2] = v.z; tile[rr][cc + 3] = v.w;
     }
     __syncthreads();
+    const int64_t O0 = transpose ? c0 : r0, OC0 = transpose ? r0 : c0;   // the destination tile's origin
+    auto at = [&](int o, int oc) { return transpose ? tile[oc][o] : tile[o][oc]; };
+    if (dst_vec && TT) {
+      // fragment-major [n / (16 T)][k / 32][T][64 lanes][8]: tile ti of a group holds as its row i the group's row
+      // 4 T (i >> 2) + 4 ti + (i & 3), lane (i, gk) the elements k = 8 gk .. 8 gk + 7 of it.  The 64 x 64 tile
+      // holds 4 / T groups x T tiles x 2 K-steps = 8 fragments; a wave writes two of them.
+      const int64_t ksteps = (ld > 0 ? ld : ncol) >> 5;  // K-steps of the whole destination (this entry may be a K slice of it)
+      const int i_row = lane & 15, gk = lane >> 4;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      // transposed: this thread writes dst[c0 + ty + 8i][r0 + tx]; plain: dst[r0 + ty + 8i][c0 + tx]
-      const int64_t orow = (transpose ? c0 : r0) + ty + 8 * i, ocol = (transpose ? r0 : c0) + tx;
-      const int64_t nrow = transpose ? C : R, ncol = transpose ? R : C;
-      if (orow < nrow && ocol < ncol) {
-        const float v = transpose ? tile[tx][ty + 8 * i] : tile[ty + 8 * i][tx];
-        if (fm_tiles) {
-          // element (n = orow, k = ocol) of the [nrow][ncol] matrix in the fragment-major layout
-          // [n / (16 T)][k / 32][T][64 lanes][8]: the wave that owns the group's 16 T output columns loads, per
-          // K-step and tile, 1 KB of consecutive bytes; tile ti holds as its row i the group's column
-          // 4 T (i >> 2) + 4 ti + (i & 3), lane (i, gk) the elements k = 8 gk .. 8 gk + 7 of it.
-          const int TT = fm_tiles;
-          const int64_t G = orow / (16 * TT);
-          const int j = (int)(orow % (16 * TT));
-          const int i_row = 4 * (j / (4 * TT)) + (j & 3), ti = (j % (4 * TT)) >> 2;
-          const int kk = (int)(ocol & 31);
-          const int64_t ksteps = (ld > 0 ? ld : ncol) >> 5;  // K-steps of the whole destination (this entry may be a K slice of it)
-          const int64_t idx = ((((G * ksteps + (ocol >> 5)) * TT + ti) * 64) + i_row + 16 * (kk >> 3)) * 8 + (kk & 7);
-          ((bf16_t*)dp[t])[idx] = f32_to_bf16(v);
-        } else if (dst_f32) ((float*)dp[t])[orow * ld + ocol] = v;
-        else ((bf16_t*)dp[t])[orow * ld + ocol] = f32_to_bf16(v);
+      for (int i = 0; i < 2; ++i) {
+        const int u = wave * 2 + i, ks = u & 1, tg = u >> 1, ti = tg % TT, gi = tg / TT;
+        const int o = gi * 16 * TT + 4 * TT * (i_row >> 2) + 4 * ti + (i_row & 3), oc = 32 * ks + 8 * gk;
+        if (O0 + o < nrow && OC0 + oc < ncol) {
+          Vec16<bf16_t> w;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) w.set(j, at(o, oc + j));
+          const int64_t G = (O0 + o) / (16 * TT);
+          const int64_t idx = ((((G * ksteps + ((OC0 + oc) >> 5)) * TT + ti) * 64) + lane) * 8;
+          *(uint4*)((bf16_t*)dp[t] + idx) = w.v;
+        }
+      }
+    } else if (dst_vec) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int q = tid + 256 * i, o = q >> 3, oc = (q & 7) * 8;
+        if (O0 + o < nrow && OC0 + oc < ncol) {
+          bf16_t* d = (bf16_t*)dp[t] + (O0 + o) * ld + OC0 + oc;
+          if (OC0 + oc + 8 <= ncol) {
+            Vec16<bf16_t> w;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) w.set(j, at(o, oc + j));
+            *(uint4*)d = w.v;
+          } else {
+            for (int j = 0; OC0 + oc + j < ncol; ++j) d[j] = f32_to_bf16(at(o, oc + j));
+          }
+        }
+      }
+    } else {
+      for (int e = tid; e < 64 * 64; e += 256) {
+        const int o = e >> 6, oc = e & 63;
+        if (O0 + o < nrow && OC0 + oc < ncol) {
+          const float v = at(o, oc);
+          if (dst_f32) ((float*)dp[t])[(O0 + o) * ld + OC0 + oc] = v;
+          else ((bf16_t*)dp[t])[(O0 + o) * ld + OC0 + oc] = f32_to_bf16(v);
+        }
       }
     }
     __syncthreads();

@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256) void pack_index_kernel(const int32_t* __restri
 }
 
 // ---- the same bookkeeping for several batches in one launch (block = batch), with the range check of ids and
-// positions that nn.Embedding makes on the host.  A wave reads a row's ids 64 at a time (one coalesced request; four
+// positions that nn.Embedding makes on the host.  A wave reads a row's ids 64 at a time (one coalesced request; eight
 // rows' requests in flight together), counts them with a ballot; the prefix sums run over the lengths as above.
 constexpr int PACK_MAX = 4, PACK_FIELDS = 12, PACK_FACTS = 6;
 struct PackDesc {
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(1024) void pack_lens_multi_kernel(PackArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int B = d.B, L = d.L;
   int ok = 1, lo = 0x7fffffff, hi = 0, ids_ok = 1, pos_ok = 1;
-  constexpr int U = 4;
+  constexpr int U = 8;
   for (int b0 = wave; b0 < B; b0 += 16 * U) {
     int cnt[U], last[U];
 #pragma unroll
