@@ -171,11 +171,11 @@ def gemm_roofline(m, opt, batch, steps):
     # HBM-side bytes per GEMM launch from the committed counter passes of this same command (rocprofv3 --pmc
     # FETCH_SIZE and --pmc WRITE_SIZE, separate runs; tools/pmc_hbm_traffic.py): counters cannot be read in-process
     traffic, traffic_src = None, None
-    pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_hbm_traffic.json")
+    pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03_pmc_hbm_traffic.json")
     if os.path.exists(pmc):
         with open(pmc) as f:
             traffic = round(json.load(f)["hbm_bytes_per_launch"])
-        traffic_src = "profiles/r02_pmc_hbm_traffic.json (bytes per launch, cfg2)"
+        traffic_src = "profiles/r03_pmc_hbm_traffic.json (bytes per launch, cfg2)"
     out = _roofline_dict(flops, ms, n, steps)
     out["traffic"], out["traffic_source"] = traffic, traffic_src
     return out
@@ -293,11 +293,11 @@ def decode_leg(device, n_batches=10, batch=128, beam=5, max_len=150, copy_task_s
     m.eval()
     sent, tok, exact, dt, nbytes = run(m, cfg["vocab"], n_batches)
     traffic, traffic_src = None, None  # counter passes of this same leg, committed (counters cannot be read in-process)
-    pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_decode_hbm_traffic.json")
+    pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03_pmc_decode_hbm_traffic.json")
     if os.path.exists(pmc) and (batch, beam, max_len) == (128, 5, 150):
         with open(pmc) as f:
             traffic = round(json.load(f)["hbm_bytes_per_step"])
-        traffic_src = "profiles/r02_pmc_decode_hbm_traffic.json (bytes per step)"
+        traffic_src = "profiles/r03_pmc_decode_hbm_traffic.json (bytes per step)"
     out["worst_case"] = dict(model="6+6 d512 FFN2048 V35000, random weights (no EOS: all 150 steps, 640 beams alive)",
                              sentences=sent, sentences_per_sec=round(sent / dt, 1), tokens_per_sec=round(tok / dt, 1),
                              mean_output_length=round(tok / sent, 1), ms_per_step=round(dt / (n_batches * max_len) * 1e3, 4),

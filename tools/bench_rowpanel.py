@@ -42,6 +42,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rows", type=int, default=25639)
     ap.add_argument("--iters", type=int, default=30)
+    ap.add_argument("--vendor", action="store_true", help="add the vendor library (torch.mm: hipBLASLt) on the plain products")
     args = ap.parse_args()
     T, d, F, NB = args.rows, 512, 2048, 4
     dev = "cuda"
@@ -106,6 +107,22 @@ def main():
         lambda i: L.gemm(L.GEMM_NT, x512[i], ckv, T, 6144, d, d, d, out=out6144[i % 2], ldc=6144, bias=b4),
         lambda i: L.rowpanel_gemm(x512[i], fkv, 6144, bias=b4, out=out6144[i % 2], ldc=6144))
 
+    if args.vendor:   # the plain products (no epilogue beyond the cast) through torch.mm, same operands and rotation
+        print(f"rows {T}: vendor library (torch.mm) against skhip_gemm / skhip_rowpanel_gemm, no bias; microseconds (TFLOP/s)")
+        for N, K in ((512, 2048), (2048, 512), (512, 512), (512, 1536), (1536, 512), (35000, 512)):
+            xs = act(K)
+            W = par(N, K)
+            Wb, Wf = ops.compute_weight(W, bf), (ops.derived_weight("fm", [W]) if K == 512 and N % 64 == 0 and N <= 6144 else None)
+            outs = [torch.empty(T, N, dtype=bf, device=dev) for _ in range(2 if N > 4096 else NB)]
+            tv = timed(lambda i: torch.mm(xs[i], Wb.t(), out=outs[i % len(outs)]), args.iters, NB)
+            tt = timed(lambda i: L.gemm(L.GEMM_NT, xs[i], Wb, T, N, K, K, K, out=outs[i % len(outs)], ldc=N), args.iters, NB)
+            tp = timed(lambda i: L.rowpanel_gemm(xs[i], Wf, N, out=outs[i % len(outs)], ldc=N), args.iters, NB) if Wf is not None else None
+            f = fl(N, K)
+            line = f"N {N:6d} K {K:5d}: vendor {tv:8.1f} ({f / tv / 1e6:5.0f})  tiled {tt:8.1f} ({f / tt / 1e6:5.0f})"
+            if tp is not None:
+                line += f"  row panel {tp:8.1f} ({f / tp / 1e6:5.0f})"
+            print(line)
+        print()
     print(f"rows {T}: microseconds per call (TFLOP/s)")
     print(f"{'product':44s} {'tiled':>16s} {'row panel':>16s}")
     for name, t0, t1, r0, r1 in rows:

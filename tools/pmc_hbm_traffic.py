@@ -26,7 +26,7 @@ for k in sorted(fetch, key=lambda k: -(2 * fetch[k][1] + write.get(k, [0, 0.0])[
     wkb = write.get(k, [0, 0.0])[1]
     rd, wr = 2 * fkb * 1024, wkb * 1024  # gfx950 correction on reads
     rows.append((k, n, rd, wr))
-    if "gemm" in k:
+    if "gemm" in k or "panel_kernel" in k:
         gemm["launches"] += n
         gemm["read_bytes"] += rd
         gemm["write_bytes"] += wr
@@ -37,7 +37,7 @@ tot = gemm["read_bytes"] + gemm["write_bytes"]
 print(f"GEMM family: {gemm['launches']} launches, {tot / gemm['launches'] / 1e6:.1f} MB per launch "
       f"({gemm['read_bytes'] / gemm['launches'] / 1e6:.1f} read + {gemm['write_bytes'] / gemm['launches'] / 1e6:.1f} written)")
 if len(sys.argv) > 4:
-    json.dump({"kernel_family": "gemm", "launches": gemm["launches"], "steps": steps,
+    json.dump({"kernel_family": "gemm + row-panel products", "launches": gemm["launches"], "steps": steps,
                "hbm_bytes_per_launch": tot / gemm["launches"], "read_bytes_per_launch": gemm["read_bytes"] / gemm["launches"],
                "write_bytes_per_launch": gemm["write_bytes"] / gemm["launches"],
                "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes; FETCH_SIZE doubled (gfx950)"},
