@@ -409,11 +409,15 @@ int skhip_beam_topk_stats(const float* logits, const float* stats, const float* 
  *    Kcache, Vcache bf16 [R][Tc][512], encK, encV bf16 [n_sent][Ls][512]}   (all 16-byte aligned).
  * tok, pos int64 [R]; cur_len int32 [R] (history length of row r including the new position); row_pad uint8 [R];
  * pad_hist uint8 [R][Tc]; hist int32 [R][Tc] (history-row table as for skhip_decode_attn); src_key_pad uint8
- * [n_sent][Ls]; dec_out bf16 [R][512].  R <= 32 x (CUs / 8) rows, sentence of row r = r / bm.
+ * [n_sent][Ls]; dec_out bf16 [R][512].  R <= 32 x min(32, CUs / 8) rows, sentence of row r = r / bm.
  * workspace: skhip_decode_stack_ws_bytes(R) bytes, 256-byte aligned, whose first 1024 bytes the caller zeroes ONCE
  * before the first call of a decode run; parity: 0 / 1, alternating from call to call (the launch of one parity
- * resets the team counters of the other).  The first 1024 bytes end with an error word (int32 at byte 256): non-zero
- * after a step means a team member stopped waiting for its team (results invalid).                               */
+ * resets the team counters and XCC masks of the other).  The first 1024 bytes hold, as int32 words: [0, 64) team
+ * counters, word 64 (byte 256) the ERROR WORD, [96, 160) per-team masks of the XCCs the team's workgroups ran on.
+ * Error word after a step: 0 = fine; 1 = a team member stopped waiting for its team; 2 = the workgroups of a team
+ * ran on more than one XCC (the exchange through their common L2 is then not coherent).  Non-zero: the results of
+ * the step, and of every later step built on it, are invalid — run the batch again through the op-by-op entry
+ * points (specialk_amd.decode.BeamDecoder.run does).                                                             */
 int64_t skhip_decode_stack_ws_bytes(int R);
 int skhip_decode_stack(const int64_t* layers, int n_layers, const int64_t* tok, const int64_t* pos,
                        const float* word_emb, const float* pos_tab, const int32_t* cur_len, const uint8_t* row_pad,
