@@ -413,7 +413,7 @@ int skhip_beam_topk_stats(const float* logits, const float* stats, const float* 
  * workspace: skhip_decode_stack_ws_bytes(R) bytes, 256-byte aligned, whose first 1024 bytes the caller zeroes ONCE
  * before the first call of a decode run; parity: 0 / 1, alternating from call to call (the launch of one parity
  * resets the team counters and XCC masks of the other).  The first 1024 bytes hold, as int32 words: [0, 64) team
- * counters, word 64 (byte 256) the ERROR WORD, [96, 160) per-team masks of the XCCs the team's workgroups ran on.
+ * counters, word 64 (byte 256) the ERROR WORD, [192, 256) per-team masks of the XCCs the team's workgroups ran on.
  * Error word after a step: 0 = fine; 1 = a team member stopped waiting for its team; 2 = the workgroups of a team
  * ran on more than one XCC (the exchange through their common L2 is then not coherent).  Non-zero: the results of
  * the step, and of every later step built on it, are invalid — run the batch again through the op-by-op entry

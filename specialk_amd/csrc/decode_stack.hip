@@ -38,6 +38,7 @@ namespace {
 constexpr int D = 512, H = 8, DH = 64, F = 2048, TEAM = 8, ROWS = 32, NTHREADS = 512;
 constexpr int MAX_LAYERS = 8, LAYER_FIELDS = 22, MAX_TEAMS = 32;
 constexpr int SPIN_LIMIT = 1 << 18;
+constexpr int XCC_WORD0 = 192;   // first of the [2][MAX_TEAMS] XCC-mask words in the workspace head (the diagnostics' time stamps sit at words 128 .. 161)
 
 struct LayerPtrs {
   const bf16_t* Wqkv; const float* bqkv;              // rows q | k | v of [1536][512], fragment-major (see load_w); [1536]
@@ -56,7 +57,7 @@ struct StackArgs {
   const int32_t* cur_len; const uint8_t* row_pad; const uint8_t* pad_hist; const int32_t* hist;
   const uint8_t* src_key_pad;
   bf16_t* dec_out;
-  int32_t* flags;   // [2][MAX_TEAMS] team counters, one error word (index 2 MAX_TEAMS), [2][MAX_TEAMS] XCC masks from index 3 MAX_TEAMS
+  int32_t* flags;   // [2][MAX_TEAMS] team counters, one error word (index 2 MAX_TEAMS), [2][MAX_TEAMS] XCC masks from index XCC_WORD0
   bf16_t* att;      // [R32][512]
   float* zbuf;      // [R32][512]
   float* pbuf;      // [8][R32][512]
@@ -867,10 +868,10 @@ __global__ __launch_bounds__(NTHREADS) void decode_stack_kernel(StackArgs a) {
   ctx.err = a.flags + 2 * MAX_TEAMS;
   ctx.count = 0;
   ctx.dead = false;
-  int32_t* const xcc_mask = a.flags + (3 + a.parity) * MAX_TEAMS + team;
+  int32_t* const xcc_mask = a.flags + XCC_WORD0 + a.parity * MAX_TEAMS + team;
   if (m0 == 0 && tid_ == 0) {   // the next step's counter and XCC mask
     a.flags[(a.parity ^ 1) * MAX_TEAMS + team] = 0;
-    a.flags[(3 + (a.parity ^ 1)) * MAX_TEAMS + team] = 0;
+    a.flags[XCC_WORD0 + (a.parity ^ 1) * MAX_TEAMS + team] = 0;
   }
   if (tid_ == 0) {   // (the first barrier waits for this request like for every other one of the wave)
     uint32_t xcc;

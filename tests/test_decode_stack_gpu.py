@@ -340,7 +340,7 @@ def test_teams_report_one_xcd_each():
     assert dec.used_stack and dec.stack_fallbacks == 0
     words = seen["ws"][:1024].view(torch.int32).cpu()
     assert int(words[L.STACK_ERR_WORD]) == 0
-    masks = words[96:160].view(2, 32)
+    masks = words[192:256].view(2, 32)
     used = masks[masks != 0]
     assert used.numel() >= 2
     assert all(bin(int(m)).count("1") == 1 for m in used), masks
