@@ -455,6 +455,8 @@ def main():
     pending = m.plan_ahead(*batches[0]) if PACKED else None
     for i in range(args.warmup):
         pending = step(i, pending)
+    from specialk_amd import ops as _ops
+    _ops.settle_host_garbage()  # as the trainer does at the start of an epoch: no full garbage collection (100 ms) inside a step
     torch.cuda.synchronize()
     if dist_on:
         dist.barrier()

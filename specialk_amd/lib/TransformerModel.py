@@ -166,6 +166,7 @@ class TransformerModel(NMTModel):
             m.generator.train(not o.freeze_decoder)
         totals = torch.zeros(3, dtype=torch.float64, device=self.device)
         want_packed = not (validation and o.log)
+        ops.settle_host_garbage()  # no 100 ms collection pause inside the steps that follow
 
         def staged():
             """Batches one step ahead of their use: batch k + 1 is copied to the device and its packing plan

@@ -361,6 +361,16 @@ def batched_weight_grads(on_ready=None, flush_tiles=256):
         _pending_dres.clear()
 
 
+def settle_host_garbage():
+    """Collect the interpreter's garbage now and move everything that survives into the permanent generation
+    (gc.freeze): a full collection walks every object torch and the model have created — 100 ms here, which lands in
+    the middle of some training step every few dozen steps — while after the freeze it only walks what was created
+    since.  Called by the trainer at the start of an epoch and by bench.py after its warm-up steps."""
+    import gc
+    gc.collect()
+    gc.freeze()
+
+
 def _reducer():
     """The data-parallel reducer whose mark_ready the current batched_weight_grads() context reports to, if it
     hands out its bucket slices (claim), else None."""
