@@ -410,9 +410,9 @@ int skhip_beam_topk_stats(const float* logits, const float* stats, const float* 
  * tok, pos int64 [R]; cur_len int32 [R] (history length of row r including the new position); row_pad uint8 [R];
  * pad_hist uint8 [R][Tc]; hist int32 [R][Tc] (history-row table as for skhip_decode_attn); src_key_pad uint8
  * [n_sent][Ls]; dec_out bf16 [R][512].  R <= 32 x min(32, CUs / 8) rows, sentence of row r = r / bm.
- * workspace: skhip_decode_stack_ws_bytes(R) bytes, 256-byte aligned, whose first 1024 bytes the caller zeroes ONCE
- * before the first call of a decode run; parity: 0 / 1, alternating from call to call (the launch of one parity
- * resets the team counters and XCC masks of the other).  The first 1024 bytes hold, as int32 words: [0, 64) team
+ * workspace: skhip_decode_stack_ws_bytes(R) bytes, 256-byte aligned, which the caller zeroes ONCE before the first
+ * call of a decode run (the team barriers' words: the first 1024 bytes and the last 4096); parity: 0 / 1, alternating
+ * from call to call (the launch of one parity resets the barrier words and XCC masks of the other).  The first 1024 bytes hold, as int32 words: [0, 64) team
  * counters, word 64 (byte 256) the ERROR WORD, [192, 256) per-team masks of the XCCs the team's workgroups ran on.
  * Error word after a step: 0 = fine; 1 = a team member stopped waiting for its team; 2 = the workgroups of a team
  * ran on more than one XCC (the exchange through their common L2 is then not coherent).  Non-zero: the results of

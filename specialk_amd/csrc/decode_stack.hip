@@ -57,6 +57,7 @@ struct StackArgs {
   const int32_t* cur_len; const uint8_t* row_pad; const uint8_t* pad_hist; const int32_t* hist;
   const uint8_t* src_key_pad;
   bf16_t* dec_out;
+  int32_t* slots;   // [2][MAX_TEAMS][16] arrival words (slot form of the team barrier) or null
   int32_t* flags;   // [2][MAX_TEAMS] team counters, one error word (index 2 MAX_TEAMS), [2][MAX_TEAMS] XCC masks from index XCC_WORD0
   bf16_t* att;      // [R32][512]
   float* zbuf;      // [R32][512]
@@ -85,35 +86,60 @@ constexpr int L_XACC = L_A, L_XML = L_A + XSEG_MAX * ROWS * DH * 4;
 static_assert(L_XML + XSEG_MAX * ROWS * 2 * 4 <= L_QKV, "segment results must fit over the A and HS images");
 
 struct TeamCtx {
-  int32_t* flag;
+  int32_t* flag;    // the team's arrival counter (counter form)
+  int32_t* slots;   // the team's eight arrival words, one 64-byte line (slot form); null: counter form
   int32_t* err;
   int count;   // barriers passed
+  int member;
   bool dead;
 };
 
 // prefetch(): loads of the NEXT phase's weights, issued by every wave between announcing its arrival and waiting for
 // the others, so that their trip to memory runs beside the barrier's own round trips.  (Issued before the barrier,
 // they sit in front of the wait for the stores, and the team meets two microseconds later.)
+// Arrival, slot form: a member STORES the number of the barrier into its own word of the team's line and polls the
+// line until all eight words have reached it — no atomic whose result has to come back before the first poll can
+// be issued (one L2 round trip less per barrier than the counter form, which the 30 barriers of a step feel).
 template <class F>
 __device__ __forceinline__ void team_sync(TeamCtx& c, F&& prefetch) {
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // this wave's stores have reached the L2
   __syncthreads();
   c.count += 1;
-  const int target = TEAM * c.count;
   const bool leader = threadIdx.x == 0 && !c.dead;
-  int seen = target;
-  // the value the increment returns already tells the last arriver that everybody is here: no poll for it
-  if (leader) seen = __hip_atomic_fetch_add(c.flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
-  prefetch();
-  if (leader) {
-    int spins = 0;
-    while (seen < target) {
-      __builtin_amdgcn_s_sleep(1);
-      seen = __hip_atomic_load(c.flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (++spins > SPIN_LIMIT) {
-        __hip_atomic_store(c.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        c.dead = true;
-        break;
+  if (c.slots) {
+    if (leader) __hip_atomic_store(c.slots + c.member, c.count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    prefetch();
+    if (leader) {
+      int spins = 0;
+      while (true) {
+        int lo = c.count;
+#pragma unroll
+        for (int i = 0; i < TEAM; ++i) lo = min(lo, __hip_atomic_load(c.slots + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        if (lo >= c.count) break;
+        if (++spins > SPIN_LIMIT) {
+          __hip_atomic_store(c.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          c.dead = true;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+    }
+  } else {
+    const int target = TEAM * c.count;
+    int seen = target;
+    // the value the increment returns already tells the last arriver that everybody is here: no poll for it
+    if (leader) seen = __hip_atomic_fetch_add(c.flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+    prefetch();
+    if (leader) {
+      int spins = 0;
+      while (seen < target) {
+        __builtin_amdgcn_s_sleep(1);
+        seen = __hip_atomic_load(c.flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (++spins > SPIN_LIMIT) {
+          __hip_atomic_store(c.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          c.dead = true;
+          break;
+        }
       }
     }
   }
@@ -868,6 +894,11 @@ __global__ __launch_bounds__(NTHREADS) void decode_stack_kernel(StackArgs a) {
   ctx.err = a.flags + 2 * MAX_TEAMS;
   ctx.count = 0;
   ctx.dead = false;
+  ctx.member = m0;
+  // slot form: [2 parities][MAX_TEAMS] lines of 16 words behind the exchange buffers; a member clears its word of
+  // the other parity's line for the next step
+  ctx.slots = a.slots ? a.slots + (a.parity * MAX_TEAMS + team) * 16 : nullptr;
+  if (a.slots && tid_ == 0) a.slots[((a.parity ^ 1) * MAX_TEAMS + team) * 16 + m0] = 0;
   int32_t* const xcc_mask = a.flags + XCC_WORD0 + a.parity * MAX_TEAMS + team;
   if (m0 == 0 && tid_ == 0) {   // the next step's counter and XCC mask
     a.flags[(a.parity ^ 1) * MAX_TEAMS + team] = 0;
@@ -1285,7 +1316,7 @@ __global__ __launch_bounds__(NTHREADS) void decode_stack_kernel(StackArgs a) {
 
 extern "C" int64_t skhip_decode_stack_ws_bytes(int R) {
   const int64_t R32 = (R + 31) / 32 * 32;
-  return 1024 + R32 * 512 * 2 + R32 * 512 * 4 + 8 * R32 * 512 * 4;
+  return 1024 + R32 * 512 * 2 + R32 * 512 * 4 + 8 * R32 * 512 * 4 + 2 * MAX_TEAMS * 64;
 }
 
 extern "C" int skhip_decode_stack(const int64_t* layers, int n_layers, const int64_t* tok, const int64_t* pos,
@@ -1334,6 +1365,8 @@ extern "C" int skhip_decode_stack(const int64_t* layers, int n_layers, const int
   a.att = (bf16_t*)(ws + 1024);
   a.zbuf = (float*)(ws + 1024 + (int64_t)R32 * 512 * 2);
   a.pbuf = (float*)(ws + 1024 + (int64_t)R32 * 512 * 2 + (int64_t)R32 * 512 * 4);
+  a.slots = (int32_t*)(ws + 1024 + (int64_t)R32 * 512 * 2 + (int64_t)R32 * 512 * 4 + 8 * (int64_t)R32 * 512 * 4);
+  { const char* e = getenv("SKHIP_STACK_SLOTS"); if (e && e[0] == '0') a.slots = nullptr; }
   a.n_layers = n_layers; a.R = R; a.R32 = R32; a.bm = bm; a.Tc = Tc; a.Ls = Ls; a.parity = parity; a.rpt = rpt;
   a.teams_pad = (n_teams + 7) / 8 * 8;   // members of a team sit at the same block index modulo 8
   a.scale = scale; a.eps = eps;
