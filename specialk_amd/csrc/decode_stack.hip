@@ -58,6 +58,7 @@ struct StackArgs {
   const uint8_t* src_key_pad;
   bf16_t* dec_out;
   int32_t* slots;   // [2][MAX_TEAMS][16] arrival words (slot form of the team barrier) or null
+  int scalar_poll;  // poll the arrival words with scalar loads
   int32_t* flags;   // [2][MAX_TEAMS] team counters, one error word (index 2 MAX_TEAMS), [2][MAX_TEAMS] XCC masks from index XCC_WORD0
   bf16_t* att;      // [R32][512]
   float* zbuf;      // [R32][512]
@@ -92,6 +93,7 @@ struct TeamCtx {
   int count;   // barriers passed
   int member;
   bool dead;
+  bool scalar_poll;
 };
 
 // prefetch(): loads of the NEXT phase's weights, issued by every wave between announcing its arrival and waiting for
@@ -113,8 +115,22 @@ __device__ __forceinline__ void team_sync(TeamCtx& c, F&& prefetch) {
       int spins = 0;
       while (true) {
         int lo = c.count;
+        if (c.scalar_poll) {
+          // The eight words by ONE scalar load that bypasses the scalar cache (glc): scalar loads have a counter of
+          // their own, so the poll does not queue behind the weight prefetch that this wave has just issued (vector
+          // loads return in the order of their issue: a vector poll waited out the whole prefetch).
+          typedef uint32_t u32x8_t __attribute__((ext_vector_type(8)));
+          u32x8_t w;
+          const uint64_t pa = (uint64_t)c.slots;
+          const uint32_t plo = __builtin_amdgcn_readfirstlane((uint32_t)pa), phi = __builtin_amdgcn_readfirstlane((uint32_t)(pa >> 32));
+          const uint64_t sp = ((uint64_t)phi << 32) | plo;
+          asm volatile("s_load_dwordx8 %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(w) : "s"(sp) : "memory");
 #pragma unroll
-        for (int i = 0; i < TEAM; ++i) lo = min(lo, __hip_atomic_load(c.slots + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+          for (int i = 0; i < TEAM; ++i) lo = min(lo, (int)w[i]);
+        } else {
+#pragma unroll
+          for (int i = 0; i < TEAM; ++i) lo = min(lo, __hip_atomic_load(c.slots + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        }
         if (lo >= c.count) break;
         if (++spins > SPIN_LIMIT) {
           __hip_atomic_store(c.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -895,6 +911,7 @@ __global__ __launch_bounds__(NTHREADS) void decode_stack_kernel(StackArgs a) {
   ctx.count = 0;
   ctx.dead = false;
   ctx.member = m0;
+  ctx.scalar_poll = a.scalar_poll;
   // slot form: [2 parities][MAX_TEAMS] lines of 16 words behind the exchange buffers; a member clears its word of
   // the other parity's line for the next step
   ctx.slots = a.slots ? a.slots + (a.parity * MAX_TEAMS + team) * 16 : nullptr;
@@ -1367,6 +1384,7 @@ extern "C" int skhip_decode_stack(const int64_t* layers, int n_layers, const int
   a.pbuf = (float*)(ws + 1024 + (int64_t)R32 * 512 * 2 + (int64_t)R32 * 512 * 4);
   a.slots = (int32_t*)(ws + 1024 + (int64_t)R32 * 512 * 2 + (int64_t)R32 * 512 * 4 + 8 * (int64_t)R32 * 512 * 4);
   { const char* e = getenv("SKHIP_STACK_SLOTS"); if (e && e[0] == '0') a.slots = nullptr; }
+  { const char* e = getenv("SKHIP_STACK_SPOLL"); a.scalar_poll = !(e && e[0] == '0'); }
   a.n_layers = n_layers; a.R = R; a.R32 = R32; a.bm = bm; a.Tc = Tc; a.Ls = Ls; a.parity = parity; a.rpt = rpt;
   a.teams_pad = (n_teams + 7) / 8 * 8;   // members of a team sit at the same block index modulo 8
   a.scale = scale; a.eps = eps;
