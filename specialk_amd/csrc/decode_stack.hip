@@ -1249,14 +1249,23 @@ __global__ __launch_bounds__(NTHREADS) void decode_stack_kernel(StackArgs a) {
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc[t][0] = acc[t][1] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     mma_rows_tiles<4, 8>(acc, w2, HS, 512, 0, l15, g);
+    // The accumulators hold, per lane, four columns of each 16-column tile: stored as they are, an instruction writes
+    // 64-byte pieces of sixteen rows, partial lines that the barrier's wait for the stores then sits out (6 us).
+    // Through a wave-private 4 KB of LDS (the attention image, idle here; rows padded by 16 bytes) they leave as the
+    // wave's whole 256 bytes of four rows per instruction.
+    float* scr = (float*)(wave < 6 ? A + wave * 4352 : (char*)QKV + (wave - 6) * 4352);   // [16][68] floats (the q | k | v image is idle as well)
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int col = 64 * wave + 16 * t + 4 * g;
+    for (int mi = 0; mi < 2; ++mi) {
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi) {
-        const int rg = row0 + 16 * mi + l15;
-        if (rg < R) *(float4*)(a.pbuf + ((int64_t)m * a.R32 + rg) * D + col) = make_float4(acc[t][mi][0], acc[t][mi][1], acc[t][mi][2], acc[t][mi][3]);
+      for (int t = 0; t < 4; ++t) *(f32x4_t*)(scr + l15 * 68 + 16 * t + 4 * g) = acc[t][mi];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int r = 4 * i + (lane >> 4), rg = row0 + 16 * mi + r;
+        const f32x4_t v = *(const f32x4_t*)(scr + r * 68 + 4 * (lane & 15));
+        if (rg < R) *(f32x4_t*)(a.pbuf + ((int64_t)m * a.R32 + rg) * D + 64 * wave + 4 * (lane & 15)) = v;
       }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
     }
     STAMP();  // 12: after G
