@@ -1,5 +1,5 @@
 #!/bin/bash
-# Copies the summaries of gpurun_out/r03 (tools/profile_r03.sh) into profiles/ under the round's prefix.
+# Copies the summaries of gpurun_out/r03 (tools/profile_r03.sh) into profiles/ with the r03_ prefix.
 set -e
 O=gpurun_out/r03; P=profiles
 cp $O/bench_cfg2.json $P/r03_bench_cfg2.json

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Evidence of the round on one MI355X: the bench lines, per-kernel time of the training step and of the decode loop,
+# Evidence run on one MI355X: the bench lines, per-kernel time of the training step and of the decode loop,
 # HBM-side byte counters and matrix-pipe busy counters (each counter set in a --pmc pass of its own), the per-shape
 # GEMM table, the vendor library on the same shapes and the in-kernel clock under load.  Run from the repository root
 # through gpurun; results land in gpurun_out/r03/.  Every GPU step has its own time limit; the script stops at the
