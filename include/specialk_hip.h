@@ -384,13 +384,32 @@ int skhip_beam_topk(const float* logits, const float* scores_in, float* scores_o
                     int first_step, int normalize, void* stream);
 
 /* skhip_beam_topk (normalize = 1) for rows whose generator product was run with SK_EPI_ROWSTATS: `stats` is that
- * call's aux output (fp32 [n_sent*bm][ceil(V/64)][2]).  The normaliser comes from the statistics and only the 64-column
- * chunks that can hold one of a row's best bm tokens are read, instead of every row twice.  Same candidates, same
- * order and tie rule; scores agree with skhip_beam_topk to fp32 rounding (the exponentials are summed chunk by chunk,
- * with the hardware exponential).  V <= 65 536.  ws as for skhip_beam_topk.                                        */
+ * call's aux output (fp32 [n_sent*bm][ceil(V/chunk_cols)][2], chunk_cols = 64), or come from
+ * skhip_generator_rowstats (chunk_cols = skhip_generator_chunk_cols()).  The normaliser comes from the statistics and
+ * only the chunks that can hold one of a row's best bm tokens are read, instead of every row twice.  Same candidates,
+ * same order and tie rule; scores agree with skhip_beam_topk to fp32 rounding (the exponentials are summed chunk by
+ * chunk, with the hardware exponential).  chunk_cols in 1..64, V <= 1024 chunk_cols.  ws as for skhip_beam_topk.   */
 int skhip_beam_topk_stats(const float* logits, const float* stats, const float* scores_in, float* scores_out,
                           int32_t* prev_out, int32_t* tok_out, void* ws, int n_sent, int bm, int64_t V,
-                          int first_step, void* stream);
+                          int first_step, int chunk_cols, void* stream);
+
+/* The generator product of a decode step with its chunk statistics, for d_model = K = 512 (bf16): logits [R][V] =
+ * x [R][K] (row stride ldx) times w [V][K] transposed, fp32 — `self.model.generator(dec_output)` of
+ * Translator.predict_word (lib/transformer/Translator.py:136-137; the log_softmax of :137 is taken by
+ * skhip_beam_topk_stats / skhip_beam_step from the statistics) — and stats [R][ceil(V/c)][2], c =
+ * skhip_generator_chunk_cols(): per row and c-column chunk the maximum and the sum of exponentials against it.  Same
+ * results as skhip_gemm(SK_GEMM_NT, SK_EPI_ROWSTATS) up to the chunk width; a workgroup owns 144 vocabulary entries
+ * and every row, so the weight is read once and the launch is one round of the chip for V up to 36 864.
+ * x_layout: SK_ROWS_PLAIN (row r at x + r * ldx) or SK_ROWS_FRAGMENT_MAJOR, the order the kernel's MFMA operands are
+ * read in, which skhip_decode_stack can write (ldx ignored): 16-byte piece c (eight elements) of row r at element
+ * offset (((r / 16) * 16 + c / 4) * 64 + 16 * (c % 4) + r % 16) * 8, in a buffer of ceil(R / 16) * 16 rows — a load
+ * instruction of a wave then fetches 1 KB of consecutive bytes instead of 64 bytes from each of 16 rows 1 KB apart,
+ * which costs the plain layout about a third more time.                                                             */
+#define SK_ROWS_PLAIN 0
+#define SK_ROWS_FRAGMENT_MAJOR 1
+int skhip_generator_chunk_cols(void);
+int skhip_generator_rowstats(const void* x, int64_t ldx, int x_layout, const void* w, float* logits, float* stats,
+                             int64_t R, int64_t V, int64_t K, void* stream);
 
 /* One decode step of the WHOLE decoder stack in one launch (bf16; d_model 512, 8 heads of 64, d_inner 2048 — other
  * shapes: SK_ERR_ARG, use the entry points above op by op).  Replaces, for the newest position of every beam row,
@@ -423,7 +442,7 @@ int skhip_decode_stack(const int64_t* layers, int n_layers, const int64_t* tok, 
                        const float* word_emb, const float* pos_tab, const int32_t* cur_len, const uint8_t* row_pad,
                        const uint8_t* pad_hist, const int32_t* hist, const uint8_t* src_key_pad, void* dec_out,
                        void* workspace, int64_t workspace_bytes, int R, int bm, int Tc, int Ls, int d_model, int n_head,
-                       int d_head, int d_inner, float scale, float eps, int parity, void* stream);
+                       int d_head, int d_inner, float scale, float eps, int parity, int out_layout, void* stream);
 
 /* The bookkeeping between two decoder steps of the beam search, for all sentences, in one launch:
  * Beam.advance's state update (lib/transformer/Beam.py:64-79: scores, prev_ks, next_ys, the EOS test on the
@@ -442,14 +461,14 @@ int skhip_beam_update(const float* new_scores, const int32_t* prev, const int32_
 
 /* skhip_beam_topk_stats followed by skhip_beam_update in ONE launch (a workgroup per sentence, a wave per beam row):
  * Beam.advance and the bookkeeping around it as cited at those two (lib/transformer/Beam.py:46-79,
- * lib/transformer/Translator.py:113-168), with the same arguments, bytes and results — new_scores / prev / new_tok
+ * lib/transformer/Translator.py:113-168), with the same arguments (chunk_cols as there), bytes and results — new_scores / prev / new_tok
  * [n_sent][bm] are still written — and `scores` both the beams' scores going in and the updated state.  Inside a
  * replayed graph a step then crosses one kernel boundary for this work instead of three.                          */
 int skhip_beam_step(const float* logits, const float* stats, float* new_scores, int32_t* prev, int32_t* new_tok,
                     void* ws, float* scores, int32_t* ys, int32_t* ks, int32_t* done, int32_t* length,
                     int32_t* n_done, int32_t* cur_len, int64_t* tok, int64_t* pos, uint8_t* row_pad,
                     uint8_t* pad_hist, const int32_t* hist_in, int32_t* hist_out, int n_sent, int bm, int64_t V,
-                    int first_step, int Tc, int max_len, int pad_id, int eos_id, void* stream);
+                    int first_step, int Tc, int max_len, int pad_id, int eos_id, int chunk_cols, void* stream);
 
 /* Reorder a cache after a beam step: dst[r] = src[src_row[r]] for rows of `row_elems`
  * elements (replaces re-building dec_seq from back-pointers every step, Beam.py:90-110,

@@ -26,6 +26,7 @@ EXPORTS = [
     "skhip_decode_stack_ws_bytes", "skhip_decode_stack", "skhip_beam_topk_stats", "skhip_beam_step",
     "skhip_softmax_rows", "skhip_conv_windows", "skhip_cnn_head", "skhip_collate", "skhip_set_reserved_cus",
     "skhip_rowpanel_rows", "skhip_rowpanel_pattern_bytes", "skhip_rowpanel_set_stamps", "skhip_rowpanel_gemm", "skhip_rowpanel_gemm_ln",
+    "skhip_generator_chunk_cols", "skhip_generator_rowstats",
 ]
 
 _lib = None
@@ -75,18 +76,19 @@ def load():
     lib.skhip_convert.argtypes = [c_p, c_p, c_i64, c_int, c_int, c_p]
     lib.skhip_decode_attn.argtypes = [c_p] * 9 + [c_i64] + [c_int] * 6 + [c_i64, c_i64, c_f32, c_int, c_int, c_p]
     lib.skhip_beam_topk.argtypes = [c_p] * 6 + [c_int, c_int, c_i64, c_int, c_int, c_p]
-    lib.skhip_beam_topk_stats.argtypes = [c_p] * 7 + [c_int, c_int, c_i64, c_int, c_p]
+    lib.skhip_beam_topk_stats.argtypes = [c_p] * 7 + [c_int, c_int, c_i64, c_int, c_int, c_p]
     lib.skhip_beam_update.argtypes = [c_p] * 16 + [c_int] * 6 + [c_p]
-    lib.skhip_beam_step.argtypes = [c_p] * 19 + [c_int, c_int, c_i64] + [c_int] * 5 + [c_p]
+    lib.skhip_beam_step.argtypes = [c_p] * 19 + [c_int, c_int, c_i64] + [c_int] * 6 + [c_p]
     lib.skhip_decode_stack_ws_bytes.argtypes = [c_int]
     lib.skhip_decode_stack_ws_bytes.restype = c_i64
-    lib.skhip_decode_stack.argtypes = [c_p, c_int] + [c_p] * 11 + [c_i64] + [c_int] * 8 + [c_f32, c_f32, c_int, c_p]
+    lib.skhip_decode_stack.argtypes = [c_p, c_int] + [c_p] * 11 + [c_i64] + [c_int] * 8 + [c_f32, c_f32, c_int, c_int, c_p]
     lib.skhip_gather_rows.argtypes = [c_p] * 3 + [c_i64] * 4 + [c_int, c_p]
     lib.skhip_rowpanel_set_stamps.argtypes = [c_p]
     lib.skhip_rowpanel_pattern_bytes.argtypes = [c_i64, c_i64]
     lib.skhip_rowpanel_pattern_bytes.restype = c_i64
     lib.skhip_rowpanel_gemm.argtypes = [c_p, c_i64, c_p, c_p, c_p, c_i64, c_p, c_i64, c_i64, c_int, c_p]
     lib.skhip_rowpanel_gemm_ln.argtypes = [c_p, c_i64, c_p, c_p, c_p, c_i64] + [c_p] * 7 + [c_i64, c_f32, c_f32, c_u64, c_p]
+    lib.skhip_generator_rowstats.argtypes = [c_p, c_i64, c_int, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_p]
     for name in EXPORTS:
         getattr(lib, name)  # AttributeError here means header and library disagree
     _lib = lib
@@ -537,15 +539,56 @@ def beam_topk(logits, scores_in, n_sent, bm, first_step, normalize=True, out=Non
     return scores_out, prev, tok
 
 
-def beam_topk_stats(logits, stats, scores_in, n_sent, bm, first_step, out):
-    """beam_topk for logits whose generator product left chunk statistics (EPI_ROWSTATS) in `stats`."""
+def generator_chunk_cols():
+    return int(load().skhip_generator_chunk_cols())
+
+
+ROWS_PLAIN, ROWS_FRAGMENT_MAJOR = 0, 1
+
+
+def fragment_major_rows(x):
+    """x [R][K] (K a multiple of 32) in the order skhip_generator_rowstats reads MFMA operands in
+    (ROWS_FRAGMENT_MAJOR): a [ceil(R / 16) * 16][K] tensor, rows past R zero."""
+    R, K = x.shape
+    nb = (R + 15) // 16
+    xp = torch.zeros((nb * 16, K), dtype=x.dtype, device=x.device)
+    xp[:R] = x
+    return xp.view(nb, 16, K // 32, 4, 8).permute(0, 2, 3, 1, 4).contiguous().view(nb * 16, K)
+
+
+def plain_rows(xfm, R):
+    """The inverse of fragment_major_rows: rows [R][K]."""
+    n16, K = xfm.shape
+    return xfm.view(n16 // 16, K // 32, 4, 16, 8).permute(0, 3, 1, 2, 4).reshape(n16, K)[:R]
+
+
+def generator_rowstats(x, w, logits, stats, x_layout=ROWS_PLAIN):
+    """logits [R][V] fp32 = x [R][512] @ w [V][512]^T (bf16) and the chunk statistics the beam top-k reads
+    (stats [R][ceil(V / generator_chunk_cols())][2]).  x_layout ROWS_FRAGMENT_MAJOR: x is fragment_major_rows of the
+    rows (what decode_stack writes on request)."""
+    R, V = logits.shape
+    K = w.shape[1]
+    assert x.dtype == w.dtype == torch.bfloat16 and w.is_contiguous() and w.shape[0] == V and x.shape[1] == K
+    assert x.stride(1) == 1 and (x_layout == ROWS_PLAIN and x.shape[0] == R or
+                                 x_layout == ROWS_FRAGMENT_MAJOR and x.is_contiguous() and x.shape[0] == (R + 15) // 16 * 16)
+    assert logits.dtype == stats.dtype == torch.float32 and logits.is_contiguous()
+    assert stats.numel() >= R * ((V + generator_chunk_cols() - 1) // generator_chunk_cols()) * 2
+    rc = load().skhip_generator_rowstats(_ptr(x), x.stride(0), int(x_layout), _ptr(w), _ptr(logits), _ptr(stats), R, V, K,
+                                         _stream())
+    _check(rc, "skhip_generator_rowstats")
+
+
+def beam_topk_stats(logits, stats, scores_in, n_sent, bm, first_step, out, chunk_cols=64):
+    """beam_topk for logits whose generator product left chunk statistics (EPI_ROWSTATS: 64 columns per chunk;
+    generator_rowstats: generator_chunk_cols()) in `stats`."""
     lib = load()
     V = logits.shape[-1]
     scores_out, prev, tok = out
-    assert logits.dtype == stats.dtype == torch.float32 and stats.numel() >= n_sent * bm * ((V + 63) // 64) * 2
+    assert logits.dtype == stats.dtype == torch.float32
+    assert stats.numel() >= n_sent * bm * ((V + chunk_cols - 1) // chunk_cols) * 2
     ws = workspace(int(lib.skhip_beam_topk_ws_bytes(n_sent, bm, V)))
     rc = lib.skhip_beam_topk_stats(_ptr(logits), _ptr(stats), _ptr(scores_in), _ptr(scores_out), _ptr(prev), _ptr(tok),
-                                   _ptr(ws), n_sent, bm, V, int(first_step), _stream())
+                                   _ptr(ws), n_sent, bm, V, int(first_step), int(chunk_cols), _stream())
     _check(rc, "skhip_beam_topk_stats")
     return scores_out, prev, tok
 
@@ -563,19 +606,20 @@ def beam_update(new_scores, prev, new_tok, scores, ys, ks, done, length, n_done,
 
 
 def beam_step(logits, stats, out, scores, ys, ks, done, length, n_done, cur_len, tok, pos, row_pad, pad_hist, hist_in,
-              hist_out, n_sent, bm, first_step, Tc, max_len, pad_id, eos_id):
+              hist_out, n_sent, bm, first_step, Tc, max_len, pad_id, eos_id, chunk_cols=64):
     """beam_topk_stats + beam_update in one launch; out = (new_scores, prev, new_tok) as for beam_topk_stats."""
     lib = load()
     V = logits.shape[-1]
     new_scores, prev, new_tok = out
-    assert logits.dtype == stats.dtype == torch.float32 and stats.numel() >= n_sent * bm * ((V + 63) // 64) * 2
+    assert logits.dtype == stats.dtype == torch.float32
+    assert stats.numel() >= n_sent * bm * ((V + chunk_cols - 1) // chunk_cols) * 2
     assert done.dtype == length.dtype == n_done.dtype == cur_len.dtype == torch.int32
     assert tok.dtype == pos.dtype == torch.int64 and row_pad.dtype == pad_hist.dtype == torch.uint8
     ws = workspace(int(lib.skhip_beam_topk_ws_bytes(n_sent, bm, V)))
     rc = lib.skhip_beam_step(_ptr(logits), _ptr(stats), _ptr(new_scores), _ptr(prev), _ptr(new_tok), _ptr(ws), _ptr(scores),
                              _ptr(ys), _ptr(ks), _ptr(done), _ptr(length), _ptr(n_done), _ptr(cur_len), _ptr(tok), _ptr(pos),
                              _ptr(row_pad), _ptr(pad_hist), _ptr(hist_in), _ptr(hist_out), n_sent, bm, V, int(first_step),
-                             Tc, max_len, pad_id, eos_id, _stream())
+                             Tc, max_len, pad_id, eos_id, int(chunk_cols), _stream())
     _check(rc, "skhip_beam_step")
 
 
@@ -597,14 +641,16 @@ def decode_stack_table(layer_tensors):
 
 
 def decode_stack(table, n_layers, tok, pos, word_emb, pos_tab, cur_len, row_pad, pad_hist, hist, src_key_pad, dec_out,
-                 ws, R, bm, Tc, Ls, d_model, n_head, d_head, d_inner, scale, eps, parity):
-    """One decode step of the whole decoder stack (see the header); ws: uint8 workspace tensor."""
+                 ws, R, bm, Tc, Ls, d_model, n_head, d_head, d_inner, scale, eps, parity, out_layout=0):
+    """One decode step of the whole decoder stack (see the header); ws: uint8 workspace tensor.  out_layout
+    ROWS_FRAGMENT_MAJOR: dec_out ([ceil(R / 16) * 16][d_model]) receives the rows as fragment_major_rows orders them."""
     assert tok.dtype == pos.dtype == torch.int64 and cur_len.dtype == hist.dtype == torch.int32
     assert dec_out.dtype == torch.bfloat16 and word_emb.dtype == pos_tab.dtype == torch.float32
+    assert dec_out.is_contiguous() and dec_out.numel() >= (R if out_layout == 0 else (R + 15) // 16 * 16) * d_model
     rc = load().skhip_decode_stack(table, n_layers, _ptr(tok), _ptr(pos), _ptr(word_emb), _ptr(pos_tab), _ptr(cur_len),
                                    _ptr(row_pad), _ptr(pad_hist), _ptr(hist), _ptr(src_key_pad), _ptr(dec_out), _ptr(ws),
                                    ws.numel() * ws.element_size(), R, bm, Tc, Ls, d_model, n_head, d_head, d_inner,
-                                   float(scale), float(eps), int(parity), _stream())
+                                   float(scale), float(eps), int(parity), int(out_layout), _stream())
     _check(rc, "skhip_decode_stack")
 
 

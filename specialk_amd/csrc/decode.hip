@@ -297,7 +297,7 @@ constexpr int STAT_SLOTS = 16;   // chunk statistics per lane: rows of up to 64 
 template <int KC>
 __device__ __forceinline__ void row_topk_stats(const float* logits, const float2* stats, const float* scores_in,
                                                float* cand_val, int32_t* cand_idx, int bm, int64_t V, int first_step,
-                                               int row, int lane) {
+                                               int row, int lane, int cw) {
   const int beam = row % bm;
   float* cv = cand_val + (int64_t)row * bm;
   int32_t* ci = cand_idx + (int64_t)row * bm;
@@ -305,7 +305,7 @@ __device__ __forceinline__ void row_topk_stats(const float* logits, const float2
     if (lane < bm) { cv[lane] = -INFINITY; ci[lane] = 0x7fffffff; }
     return;
   }
-  const int nchunk = (int)((V + 63) >> 6);
+  const int nchunk = (int)((V + cw - 1) / cw);   // cw: columns per statistics chunk (at most 64: a lane per column)
   const float2* st = stats + (int64_t)row * nchunk;
   float cm[STAT_SLOTS], cs[STAT_SLOTS];
   float mx = -INFINITY;
@@ -362,13 +362,14 @@ __device__ __forceinline__ void row_topk_stats(const float* logits, const float2
     float v[BATCH];
 #pragma unroll
     for (int k = 0; k < BATCH; ++k) {
-      const int64_t c = 64 * (int64_t)batch[k < nb ? k : 0] + lane;
-      v[k] = (k < nb && c < V) ? x[c < V ? c : 0] : -INFINITY;
+      const int64_t c = cw * (int64_t)batch[k < nb ? k : 0] + lane;
+      const bool in = k < nb && lane < cw && c < V;
+      v[k] = in ? x[in ? c : 0] : -INFINITY;
     }
 #pragma unroll
     for (int k = 0; k < BATCH; ++k) {
-      const int64_t c = 64 * (int64_t)batch[k < nb ? k : 0] + lane;
-      if (k < nb) visit(v[k], c < V ? (int)c : 0x7fffffff);
+      const int64_t c = cw * (int64_t)batch[k < nb ? k : 0] + lane;
+      if (k < nb) visit(v[k], lane < cw && c < V ? (int)c : 0x7fffffff);
     }
     nb = 0;
   };
@@ -404,8 +405,8 @@ __global__ __launch_bounds__(64) void beam_row_topk_stats_kernel(const float* __
                                                                  const float2* __restrict__ stats,
                                                                  const float* __restrict__ scores_in,
                                                                  float* __restrict__ cand_val, int32_t* __restrict__ cand_idx,
-                                                                 int bm, int64_t V, int first_step) {
-  row_topk_stats<KC>(logits, stats, scores_in, cand_val, cand_idx, bm, V, first_step, blockIdx.x, threadIdx.x);
+                                                                 int bm, int64_t V, int first_step, int cw) {
+  row_topk_stats<KC>(logits, stats, scores_in, cand_val, cand_idx, bm, V, first_step, blockIdx.x, threadIdx.x, cw);
 }
 
 // Pass B: one wave per sentence merges its bm*bm row candidates into the new beam,
@@ -537,10 +538,10 @@ __global__ __launch_bounds__(64) void beam_update_kernel(const float* __restrict
 template <int KC>
 __global__ __launch_bounds__(1024) void beam_step_kernel(const float* logits, const float2* stats, float* cand_val,
                                                          int32_t* cand_idx, float* new_scores, int32_t* prev,
-                                                         int32_t* new_tok, int64_t V, int first_step, BeamState st) {
+                                                         int32_t* new_tok, int64_t V, int first_step, int cw, BeamState st) {
   const int sent = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int row = sent * st.bm + wave;
-  row_topk_stats<KC>(logits, stats, st.scores, cand_val, cand_idx, st.bm, V, first_step, row, lane);
+  row_topk_stats<KC>(logits, stats, st.scores, cand_val, cand_idx, st.bm, V, first_step, row, lane, cw);
   __syncthreads();
   if (wave == 0) beam_merge(cand_val, cand_idx, new_scores, prev, new_tok, st.bm, V, sent, lane);
   __syncthreads();
@@ -612,17 +613,19 @@ extern "C" int skhip_beam_topk(const float* logits, const float* scores_in, floa
 
 extern "C" int skhip_beam_topk_stats(const float* logits, const float* stats, const float* scores_in, float* scores_out,
                                      int32_t* prev_out, int32_t* tok_out, void* ws, int n_sent, int bm, int64_t V,
-                                     int first_step, void* stream_) {
+                                     int first_step, int chunk_cols, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   SK_CHECK_ARG(bm >= 1 && bm <= 16, "skhip_beam_topk_stats: beam size %d not in 1..16", bm);
-  SK_CHECK_ARG(V >= bm && V <= 64 * 64 * STAT_SLOTS, "skhip_beam_topk_stats: V=%lld not in bm..65536", (long long)V);
+  SK_CHECK_ARG(chunk_cols >= 1 && chunk_cols <= 64, "skhip_beam_topk_stats: chunk_cols=%d not in 1..64", chunk_cols);
+  SK_CHECK_ARG(V >= bm && V <= (int64_t)chunk_cols * 64 * STAT_SLOTS, "skhip_beam_topk_stats: V=%lld not in bm..%d", (long long)V,
+               chunk_cols * 64 * STAT_SLOTS);
   if (n_sent == 0) return SK_OK;
   SK_CHECK_ARG(logits && stats && scores_in && scores_out && prev_out && tok_out && ws && (uintptr_t)stats % 8 == 0,
                "skhip_beam_topk_stats: null or misaligned pointer");
   float* cv = (float*)ws;
   int32_t* ci = (int32_t*)(cv + (int64_t)n_sent * bm * bm);
   dim3 grid((unsigned)(n_sent * bm));
-#define BEAM_S(KC) hipLaunchKernelGGL((beam_row_topk_stats_kernel<KC>), grid, dim3(64), 0, stream, logits, (const float2*)stats, scores_in, cv, ci, bm, V, first_step)
+#define BEAM_S(KC) hipLaunchKernelGGL((beam_row_topk_stats_kernel<KC>), grid, dim3(64), 0, stream, logits, (const float2*)stats, scores_in, cv, ci, bm, V, first_step, chunk_cols)
   if (bm <= 1) BEAM_S(1);
   else if (bm <= 2) BEAM_S(2);
   else if (bm <= 4) BEAM_S(4);
@@ -681,10 +684,12 @@ extern "C" int skhip_beam_step(const float* logits, const float* stats, float* n
                                void* ws, float* scores, int32_t* ys, int32_t* ks, int32_t* done, int32_t* length,
                                int32_t* n_done, int32_t* cur_len, int64_t* tok, int64_t* pos, uint8_t* row_pad,
                                uint8_t* pad_hist, const int32_t* hist_in, int32_t* hist_out, int n_sent, int bm, int64_t V,
-                               int first_step, int Tc, int max_len, int pad_id, int eos_id, void* stream_) {
+                               int first_step, int Tc, int max_len, int pad_id, int eos_id, int chunk_cols, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   SK_CHECK_ARG(bm >= 1 && bm <= 16, "skhip_beam_step: beam size %d not in 1..16", bm);
-  SK_CHECK_ARG(V >= bm && V <= 64 * 64 * STAT_SLOTS, "skhip_beam_step: V=%lld not in bm..65536", (long long)V);
+  SK_CHECK_ARG(chunk_cols >= 1 && chunk_cols <= 64, "skhip_beam_step: chunk_cols=%d not in 1..64", chunk_cols);
+  SK_CHECK_ARG(V >= bm && V <= (int64_t)chunk_cols * 64 * STAT_SLOTS, "skhip_beam_step: V=%lld not in bm..%d", (long long)V,
+               chunk_cols * 64 * STAT_SLOTS);
   SK_CHECK_ARG(n_sent >= 0 && Tc >= 1 && max_len >= 1, "skhip_beam_step: bad shape");
   if (n_sent == 0) return SK_OK;
   SK_CHECK_ARG(logits && stats && new_scores && prev && new_tok && ws && (uintptr_t)stats % 8 == 0 && scores && ys && ks &&
@@ -695,7 +700,7 @@ extern "C" int skhip_beam_step(const float* logits, const float* stats, float* n
   const BeamState st{scores, ys, ks, done, length, n_done, cur_len, tok, pos, row_pad, pad_hist, hist_in, hist_out,
                      n_sent, bm, Tc, max_len, pad_id, eos_id};
   const dim3 grid((unsigned)n_sent), block((unsigned)(64 * bm));
-#define BEAM_F(KC) hipLaunchKernelGGL((beam_step_kernel<KC>), grid, block, 0, stream, logits, (const float2*)stats, cv, ci, new_scores, prev, new_tok, V, first_step, st)
+#define BEAM_F(KC) hipLaunchKernelGGL((beam_step_kernel<KC>), grid, block, 0, stream, logits, (const float2*)stats, cv, ci, new_scores, prev, new_tok, V, first_step, chunk_cols, st)
   if (bm <= 1) BEAM_F(1);
   else if (bm <= 2) BEAM_F(2);
   else if (bm <= 4) BEAM_F(4);

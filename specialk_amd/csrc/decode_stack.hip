@@ -56,7 +56,8 @@ struct StackArgs {
   const int64_t* tok; const int64_t* pos; const float* word_emb; const float* pos_tab;
   const int32_t* cur_len; const uint8_t* row_pad; const uint8_t* pad_hist; const int32_t* hist;
   const uint8_t* src_key_pad;
-  bf16_t* dec_out;
+  bf16_t* dec_out;  // the stack's output rows, [R][512] or fragment-major (out_fm)
+  int out_fm;
   int32_t* slots;   // [2][MAX_TEAMS][16] arrival words (slot form of the team barrier) or null
   int scalar_poll;  // poll the arrival words with scalar loads
   int32_t* flags;   // [2][MAX_TEAMS] team counters, one error word (index 2 MAX_TEAMS), [2][MAX_TEAMS] XCC masks from index XCC_WORD0
@@ -1332,7 +1333,10 @@ __global__ __launch_bounds__(NTHREADS) void decode_stack_kernel(StackArgs a) {
   {
     IDS();
     const int r = (tid >> 3) & 31, c = 8 * m + (tid & 7);
-    if (tid < 256 && row0 + r < R) *(uint4*)(a.dec_out + (int64_t)(row0 + r) * D + 8 * c) = *(const uint4*)(X + r * 1024 + ((c ^ (r & 15)) << 4));
+    const int rg = row0 + r;
+    // (fragment-major: the order the generator product reads its MFMA operands in, see skhip_generator_rowstats)
+    const int64_t at = a.out_fm ? ((int64_t)((rg >> 4) * 16 + (c >> 2)) * 64 + 16 * (c & 3) + (rg & 15)) * 8 : (int64_t)rg * D + 8 * c;
+    if (tid < 256 && rg < R) *(uint4*)(a.dec_out + at) = *(const uint4*)(X + r * 1024 + ((c ^ (r & 15)) << 4));
   }
 }
 
@@ -1350,13 +1354,14 @@ extern "C" int skhip_decode_stack(const int64_t* layers, int n_layers, const int
                                   const uint8_t* row_pad, const uint8_t* pad_hist, const int32_t* hist,
                                   const uint8_t* src_key_pad, void* dec_out, void* workspace, int64_t workspace_bytes,
                                   int R, int bm, int Tc, int Ls, int d_model, int n_head, int d_head, int d_inner,
-                                  float scale, float eps, int parity, void* stream_) {
+                                  float scale, float eps, int parity, int out_layout, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   SK_CHECK_ARG(d_model == D && n_head == H && d_head == DH && d_inner == F,
                "skhip_decode_stack: built for d_model 512, 8 heads of 64, d_inner 2048 (got %d, %d x %d, %d)", d_model, n_head,
                d_head, d_inner);
   SK_CHECK_ARG(n_layers >= 1 && n_layers <= MAX_LAYERS, "skhip_decode_stack: n_layers=%d not in 1..%d", n_layers, MAX_LAYERS);
   SK_CHECK_ARG(R >= 1 && bm >= 1 && Tc >= 1 && Ls >= 1 && (parity == 0 || parity == 1), "skhip_decode_stack: bad shape");
+  SK_CHECK_ARG(out_layout == SK_ROWS_PLAIN || out_layout == SK_ROWS_FRAGMENT_MAJOR, "skhip_decode_stack: out_layout=%d", out_layout);
   // as many teams as fit the chip at one workgroup per CU (every CU then pulls its share of the keys / values
   // and of the weights), each with the same number of rows, at most 32
   const int R32 = (R + 31) / 32 * 32;
@@ -1385,7 +1390,7 @@ extern "C" int skhip_decode_stack(const int64_t* layers, int n_layers, const int
   }
   a.tok = tok; a.pos = pos; a.word_emb = word_emb; a.pos_tab = pos_tab;
   a.cur_len = cur_len; a.row_pad = row_pad; a.pad_hist = pad_hist; a.hist = hist; a.src_key_pad = src_key_pad;
-  a.dec_out = (bf16_t*)dec_out;
+  a.dec_out = (bf16_t*)dec_out; a.out_fm = out_layout == SK_ROWS_FRAGMENT_MAJOR;
   char* ws = (char*)workspace;
   a.flags = (int32_t*)ws;
   a.att = (bf16_t*)(ws + 1024);

@@ -227,13 +227,18 @@ class BeamDecoder:
                 keep.append(row)
             stack_table, _ = L.decode_stack_table(rows)
             stack_ws = torch.zeros(L.decode_stack_ws_bytes(R), dtype=torch.uint8, device=dev)
-            stack_out = torch.empty((R, d), dtype=dt, device=dev)
             ln_eps = float(layers[0].slf_attn.layer_norm.eps)
         self.used_stack = bool(stack)
         use_stats = (dt == torch.bfloat16 and d % 8 == 0 and V <= 65536 and os.environ.get("SK_DECODE_TOPK_STATS", "1") != "0")
+        # the generator product by vocabulary slabs (one round of the chip, the weight read once) when the stack
+        # kernel can hand it the rows in MFMA operand order; its statistics chunks are 48 columns wide
+        gen_slab = bool(stack) and use_stats and V <= 1024 * L.generator_chunk_cols() and os.environ.get("SK_DECODE_GEN_SLAB", "1") != "0"
+        chunk = L.generator_chunk_cols() if gen_slab else 64
+        if stack:
+            stack_out = torch.zeros(((R + 15) // 16 * 16, d), dtype=dt, device=dev)
         if use_stats:
             logits_buf = torch.empty((R, V), dtype=torch.float32, device=dev)
-            gen_stats = torch.empty((R, (V + 63) // 64, 2), dtype=torch.float32, device=dev)
+            gen_stats = torch.empty((R, (V + chunk - 1) // chunk, 2), dtype=torch.float32, device=dev)
         # (tests that force or trace a step's choices sit between the top-k and the update: they keep the separate launches)
         fused_step = (use_stats and self.forced is None and self.trace is None
                       and os.environ.get("SK_DECODE_FUSED_STEP", "1") != "0")
@@ -244,8 +249,9 @@ class BeamDecoder:
             table hist[cur] and leaves the re-parented one in hist[cur ^ 1]."""
             if stack:
                 L.decode_stack(stack_table, NL, tok, pos, word_emb, pos_tab, cur_len, row_pad, pad_hist, hist[cur],
-                               src_key_pad, stack_out, stack_ws, R, bm, Tc, Ls, d, H, dk, F, scale, ln_eps, cur)
-                return finish_step(stack_out, first, cur)
+                               src_key_pad, stack_out, stack_ws, R, bm, Tc, Ls, d, H, dk, F, scale, ln_eps, cur,
+                               L.ROWS_FRAGMENT_MAJOR if gen_slab else L.ROWS_PLAIN)
+                return finish_step(stack_out if gen_slab else stack_out[:R], first, cur)
             x = L.embed_fwd(tok, pos, word_emb, pos_tab, dt)
             for li, layer in enumerate(layers):
                 a = layer.slf_attn
@@ -270,15 +276,18 @@ class BeamDecoder:
             if use_stats:
                 # bf16 models: the generator product also leaves each 64-column chunk's maximum and sum of exponentials;
                 # the top-k then reads those and the few chunks that can hold a best token, not every row twice
-                L.gemm(L.GEMM_NT, x, gen_w, R, V, d, d, d, out=logits_buf, ldc=V, aux=gen_stats, epilogue=L.EPI_ROWSTATS,
-                       split_k=False)
+                if gen_slab:
+                    L.generator_rowstats(x, gen_w, logits_buf, gen_stats, L.ROWS_FRAGMENT_MAJOR)
+                else:
+                    L.gemm(L.GEMM_NT, x, gen_w, R, V, d, d, d, out=logits_buf, ldc=V, aux=gen_stats, epilogue=L.EPI_ROWSTATS,
+                           split_k=False)
                 if fused_step:  # top-k, merge and state update in one launch
                     L.beam_step(logits_buf, gen_stats, (new_scores, prev, new_tok), scores, ys, ks, done, length, n_done,
                                 cur_len, tok, pos, row_pad, pad_hist, hist[cur], hist[cur ^ 1], n, bm, first, Tc, Tmax,
-                                Constants.PAD, Constants.EOS)
+                                Constants.PAD, Constants.EOS, chunk_cols=chunk)
                     step_no[0] += 1
                     return
-                L.beam_topk_stats(logits_buf, gen_stats, scores, n, bm, first, out=(new_scores, prev, new_tok))
+                L.beam_topk_stats(logits_buf, gen_stats, scores, n, bm, first, out=(new_scores, prev, new_tok), chunk_cols=chunk)
             else:  # fp32 models keep expf and the reference's bits
                 logits = L.gemm(L.GEMM_NT, x, gen_w, R, V, d, d, d, out_dtype=torch.float32)
                 L.beam_topk(logits, scores, n, bm, first_step=first, normalize=2 if dt == torch.bfloat16 else 1,
@@ -287,7 +296,8 @@ class BeamDecoder:
                 for dst, src in zip((new_scores, prev, new_tok), self.forced[step_no[0]]):
                     dst.copy_(src)
             if self.trace is not None:
-                self.trace.append((x.clone(), new_scores.clone(), prev.clone(), new_tok.clone()))
+                self.trace.append(((L.plain_rows(x, R) if gen_slab and stack else x).clone(), new_scores.clone(), prev.clone(),
+                                   new_tok.clone()))
             step_no[0] += 1
             # finished sentences keep their final beam state (their Beam is no longer advanced)
             L.beam_update(new_scores, prev, new_tok, scores, ys, ks, done, length, n_done, cur_len, tok, pos, row_pad,

@@ -344,3 +344,17 @@ def test_teams_report_one_xcd_each():
     used = masks[masks != 0]
     assert used.numel() >= 2
     assert all(bin(int(m)).count("1") == 1 for m in used), masks
+
+
+def test_slab_generator_search_equals_tiled_generator_search(monkeypatch):
+    """The stack handing its rows to the vocabulary-slab generator product in fragment-major order (the default)
+    against the same search with the tiled product on row-major rows: the products are equal bit for bit, so the
+    hypotheses are the same and the scores differ by the statistics' summation order only."""
+    from specialk_amd.decode import BeamDecoder
+    m = build(2, vocab=1003)
+    src, pos = batch(37, 3, 17, 1003, 4)
+    h1, s1 = BeamDecoder(m, 5, 14, use_graph=True, use_stack=True).run(src, pos, 2)
+    monkeypatch.setenv("SK_DECODE_GEN_SLAB", "0")
+    h0, s0 = BeamDecoder(m, 5, 14, use_graph=True, use_stack=True).run(src, pos, 2)
+    assert h1 == h0
+    assert max(float((a - b).abs().max()) for a, b in zip(s0, s1)) <= 1e-4

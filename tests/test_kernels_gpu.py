@@ -1100,3 +1100,53 @@ def test_reserved_cus_change_scheduling_not_results(L):
                 L.set_reserved_cus(bad)
     finally:
         L.set_reserved_cus(0)
+
+
+@pytest.mark.parametrize("R,V,layout", [(640, 35000, 1), (640, 4999, 0), (35, 1003, 1), (35, 1003, 0), (5, 50, 1), (300, 144, 1),
+                                        (129, 1441, 0)])
+def test_generator_rowstats_equals_tiled_product(L, R, V, layout):
+    """skhip_generator_rowstats (a workgroup per 144 vocabulary entries, every row) against skhip_gemm with
+    SK_EPI_ROWSTATS: the fp32 products bit for bit (same MFMA, same order over K), the statistics of its 48-column
+    chunks against the products themselves, and the same beam choices through skhip_beam_topk_stats with either
+    chunk width; activations row-major and in the fragment-major order (fragment_major_rows and back), vocabularies
+    that end inside a chunk, inside a tile and (V = 144) with a slab."""
+    g = torch.Generator().manual_seed(7 * R + V)
+    d, bm = 512, 5
+    x = rnd((R, d), torch.bfloat16, g).to(DEV)
+    W = (rnd((V, d), torch.bfloat16, g) * 0.2).to(DEV)
+    cw = L.generator_chunk_cols()
+    assert cw == 48
+    ref = torch.empty((R, V), dtype=torch.float32, device=DEV)
+    st_ref = torch.empty((R, (V + 63) // 64, 2), dtype=torch.float32, device=DEV)
+    L.gemm(L.GEMM_NT, x, W, R, V, d, d, d, out=ref, ldc=V, aux=st_ref, epilogue=L.EPI_ROWSTATS, split_k=False)
+    got = torch.full((R, V), float("nan"), dtype=torch.float32, device=DEV)
+    nch = (V + cw - 1) // cw
+    st = torch.full((R, nch, 2), float("nan"), dtype=torch.float32, device=DEV)
+    xs = L.fragment_major_rows(x) if layout else x
+    if layout:
+        assert torch.equal(L.plain_rows(xs, R), x)
+    L.generator_rowstats(xs, W, got, st, layout)
+    assert torch.equal(got, ref)
+    pad = torch.full((R, nch * cw), float("-inf"), dtype=torch.float32, device=DEV)
+    pad[:, :V] = got
+    ch = pad.view(R, nch, cw)
+    mx = ch.max(2).values
+    assert torch.equal(st[:, :, 0], mx)
+    assert rel_err(st[:, :, 1], torch.exp(ch - mx.unsqueeze(2)).sum(2)) <= 1e-5
+    if R % bm == 0 and V >= bm:
+        n = R // bm
+        scores = -torch.rand(n, bm, generator=g).to(DEV)
+        for first in (True, False):
+            a = tuple(torch.empty((n, bm), dtype=t, device=DEV) for t in (torch.float32, torch.int32, torch.int32))
+            b = tuple(torch.empty((n, bm), dtype=t, device=DEV) for t in (torch.float32, torch.int32, torch.int32))
+            L.beam_topk_stats(ref, st_ref, scores, n, bm, first, a, chunk_cols=64)
+            L.beam_topk_stats(got, st, scores, n, bm, first, b, chunk_cols=cw)
+            assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+            assert (a[0] - b[0]).abs().max().item() <= 2e-5
+
+
+def test_generator_rowstats_rejects_other_widths(L):
+    x = torch.zeros((16, 256), dtype=torch.bfloat16, device=DEV)
+    W = torch.zeros((100, 256), dtype=torch.bfloat16, device=DEV)
+    with pytest.raises(RuntimeError, match="K must be 512"):
+        L.generator_rowstats(x, W, torch.empty((16, 100), device=DEV), torch.empty((16, 3, 2), device=DEV))
