@@ -125,8 +125,9 @@ __device__ __forceinline__ void products(const WaveCtx& c, const bf16_t* const (
 }
 
 // Products and chunk statistics of NB blocks: the lanes l15, l15 + 16, l15 + 32, l15 + 48 hold a row's 16 columns of
-// a tile.
-template <int NB>
+// a tile.  FULL: the whole slab lies inside the vocabulary and the rows of C start on 16-byte boundaries (every
+// workgroup but the last): no column is masked, every store is 16 bytes.
+template <int NB, bool FULL>
 __device__ __forceinline__ void write_out(const Params& p, const WaveCtx& c, int b0, f32x4_t (&acc)[MAXB][NT]) {
   const int g = c.g, c0 = c.c0;
 #pragma unroll
@@ -142,9 +143,9 @@ __device__ __forceinline__ void write_out(const Params& p, const WaveCtx& c, int
         const int col = c0 + 16 * (3 * q + t) + 4 * g;
         const f32x4_t v = acc[nb][3 * q + t];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) m = fmaxf(m, col + r < p.V ? v[r] : -INFINITY);
+        for (int r = 0; r < 4; ++r) m = fmaxf(m, FULL || col + r < p.V ? v[r] : -INFINITY);
         if (live) {
-          if (p.vec && col + 3 < p.V) {
+          if (FULL || (p.vec && col + 3 < p.V)) {
             *(float4*)(crow + col) = make_float4(v[0], v[1], v[2], v[3]);
           } else {
 #pragma unroll
@@ -160,9 +161,9 @@ __device__ __forceinline__ void write_out(const Params& p, const WaveCtx& c, int
       for (int t = 0; t < 3; ++t) {
         const int col = c0 + 16 * (3 * q + t) + 4 * g;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) se += col + r < p.V ? __expf(acc[nb][3 * q + t][r] - m) : 0.f;
+        for (int r = 0; r < 4; ++r) se += FULL || col + r < p.V ? __expf(acc[nb][3 * q + t][r] - m) : 0.f;
       }
-      if (m == -INFINITY) se = 0.f;
+      if (!FULL && m == -INFINITY) se = 0.f;
       se += __shfl_xor(se, 16, 64);
       se += __shfl_xor(se, 32, 64);
       const int chunk = (c0 + CW * q) / CW;
@@ -200,10 +201,11 @@ __global__ __launch_bounds__(512, 1) void slab_kernel(Params p) {
 #pragma unroll
   for (int j = 0; j < 4; ++j) c.offs[j] = ((4 * j + c.g) ^ c.l15) << 4;
   c.wa32 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem + c.l15 * WROW;
-  // wave w takes the blocks w, w + 8, .. up to two at a time; the second wave of a SIMD (waves 4 .. 7) starts with
+  // wave w takes the blocks w, w + 8, .. up to three at a time; the second wave of a SIMD (waves 4 .. 7) starts with
   // the short pass where the first one ends with it, so that the two are not in their epilogues together.  The first
   // activation fragments of a pass are requested before the stores of the pass before it (the memory counter is in
   // order: behind them, the first product of the pass would wait for every one of those stores)
+  const bool full = p.vec && c0 + SLAB <= p.V;
   const int nblk = (p.R + 15) >> 4;
   const int n = wave < nblk ? (nblk - wave + 7) >> 3 : 0;   // blocks of this wave
   auto pass_size = [&](int j) { return wave >= 4 && j == 0 && n % MAXB ? n % MAXB : min(MAXB, n - j); };
@@ -224,9 +226,15 @@ __global__ __launch_bounds__(512, 1) void slab_kernel(Params p) {
       x_pointers<XFM>(p, c, wave + 8 * j, xp);
       x_first(xp, xr, xstep);
     }
-    if (nb == 3) write_out<3>(p, c, b0, acc);
-    else if (nb == 2) write_out<2>(p, c, b0, acc);
-    else write_out<1>(p, c, b0, acc);
+    if (full) {
+      if (nb == 3) write_out<3, true>(p, c, b0, acc);
+      else if (nb == 2) write_out<2, true>(p, c, b0, acc);
+      else write_out<1, true>(p, c, b0, acc);
+    } else {
+      if (nb == 3) write_out<3, false>(p, c, b0, acc);
+      else if (nb == 2) write_out<2, false>(p, c, b0, acc);
+      else write_out<1, false>(p, c, b0, acc);
+    }
   }
 }
 
