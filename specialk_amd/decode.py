@@ -130,11 +130,48 @@ class BeamDecoder:
         model.eval()
         enc_out, *_ = model.encoder(src_seq, src_pos)
         enc2d = enc_out.reshape(n * Ls, d)
-        src_key_pad = src_seq.eq(Constants.PAD).to(torch.uint8).contiguous()
+
+        # Buffers, and the graph captured over them, are kept from call to call with the prepared weights (so: until
+        # a parameter changes) for the last two batch shapes: a batch of a known shape then costs no capture (0.6 ms),
+        # no zeroing of the caches (1.3 GB at 640 rows) and no allocations.  Kept only for the path that replays
+        # graphs of the one-launch stack; SK_DECODE_REUSE=0: everything afresh for every call.
+        F = layers[0].pos_ffn.w_1.weight.shape[0]
+        # (teams of 8 workgroups x 32 rows, at most 32 teams, all resident together at one workgroup per CU)
+        stack = (use_stack and dt == torch.bfloat16 and (d, H, dk, dv, F) == (512, 8, 64, 64, 2048) and NL <= 8
+                 and R <= 32 * min(32, torch.cuda.get_device_properties(dev).multi_processor_count // 8))
+        prep = self._prepared(layers, dt, dev)
+        gen_w = self._w(model.generator.weight, dt)
+        V = gen_w.shape[0]
+        word_emb, pos_tab = dec.tgt_word_emb.weight.detach(), dec.position_enc.weight.detach()
+        reuse = (self.use_graph and stack and self.forced is None and self.trace is None
+                 and os.environ.get("SK_DECODE_REUSE", "1") != "0")
+        B = {}
+        if reuse:
+            runs, key = prep.setdefault("runs", {}), (n, Ls, bm, Tmax)
+            ptrs = (gen_w.data_ptr(), word_emb.data_ptr(), pos_tab.data_ptr())
+            B = runs.get(key)
+            if B is None or B["ptrs"] != ptrs:
+                while len(runs) >= 2:
+                    runs.pop(next(iter(runs)))
+                B = runs[key] = {"ptrs": ptrs}
+
+        def buf(name, shape, dtype, fill=None, once=False):
+            """The call's tensor `name`: a new one, or the kept one of this batch shape; filled with `fill` (once=True:
+            only when new)."""
+            t = B.get(name)
+            new = t is None
+            if new:
+                t = B[name] = torch.empty(shape, dtype=dtype, device=dev)
+            if fill is not None and (new or not once):
+                t.fill_(fill)
+            return t
+
+        src_key_pad = buf("src_key_pad", (n, Ls), torch.uint8)
+        src_key_pad.copy_(src_seq.eq(Constants.PAD))
 
         # encoder-side K/V: once per sentence, shared by its beams
-        crossK = torch.empty((NL, n, Ls, H * dk), dtype=dt, device=dev)
-        crossV = torch.empty((NL, n, Ls, H * dv), dtype=dt, device=dev)
+        crossK = buf("crossK", (NL, n, Ls, H * dk), dt)
+        crossV = buf("crossV", (NL, n, Ls, H * dv), dt)
         for li, layer in enumerate(layers):
             a = layer.enc_attn
             L.gemm(L.GEMM_NT, enc2d, self._w(a.w_ks.weight, dt), n * Ls, H * dk, d, d, d, out=crossK[li], ldc=H * dk,
@@ -144,38 +181,38 @@ class BeamDecoder:
 
         # self-attention caches: position t of the hypothesis that occupies row r at step t is written to
         # cache row r and never moved; hist[r][j] names the cache row of position j of row r's history
-        # and is what the beam re-ordering permutes (double buffered).  Time axis rounded up to 16.
+        # and is what the beam re-ordering permutes (double buffered).  Time axis rounded up to 16.  (Kept caches
+        # are not cleared: positions past a row's length are masked where they are read, and what lies there are an
+        # earlier batch's finite keys and values.)
         Tc = (Tmax + 15) // 16 * 16
-        Kc = torch.zeros((NL, R, Tc, H * dk), dtype=dt, device=dev)
-        Vc = torch.zeros((NL, R, Tc, H * dv), dtype=dt, device=dev)
+        Kc = buf("Kc", (NL, R, Tc, H * dk), dt, 0, once=True)
+        Vc = buf("Vc", (NL, R, Tc, H * dv), dt, 0, once=True)
         i32 = dict(dtype=torch.int32, device=dev)
-        pad_hist = torch.zeros((R, Tc), dtype=torch.uint8, device=dev)
-        hist = [torch.zeros((R, Tc), **i32) for _ in range(2)]
-        hist[0][:, 0] = torch.arange(R, **i32)
+        pad_hist = buf("pad_hist", (R, Tc), torch.uint8, 0)
+        hist = [buf("hist0", (R, Tc), torch.int32, 0), buf("hist1", (R, Tc), torch.int32, 0)]
+        if "row_ids" not in B:
+            B["row_ids"] = torch.arange(R, **i32)
+        hist[0][:, 0] = B["row_ids"]
 
         # Beam state and the inputs of the next step live on the device and are advanced by one kernel per step
         # (skhip_beam_update), including the step counter (cur_len): a step's launches do not depend on the
         # step number, so pairs of steps (the history table is double buffered) are captured in a graph once
-        # per batch and replayed.
-        scores = torch.zeros((n, bm), dtype=torch.float32, device=dev)
-        new_scores = torch.empty((n, bm), dtype=torch.float32, device=dev)
-        prev, new_tok = torch.empty((n, bm), **i32), torch.empty((n, bm), **i32)
-        ys = torch.zeros((Tmax + 1, n, bm), **i32)
-        ks = torch.zeros((Tmax, n, bm), **i32)
-        done, n_done = torch.zeros(n, **i32), torch.zeros(1, **i32)
-        length = torch.full((n,), Tmax, **i32)
-        cur_len = torch.ones(R, **i32)
-        tok = torch.full((R,), Constants.SOS, dtype=torch.int64, device=dev)
-        pos = torch.ones(R, dtype=torch.int64, device=dev)
-        row_pad = torch.zeros(R, dtype=torch.uint8, device=dev)
-        gen_w = self._w(model.generator.weight, dt)
-        V = gen_w.shape[0]
-        word_emb, pos_tab = dec.tgt_word_emb.weight.detach(), dec.position_enc.weight.detach()
+        # per batch shape and replayed.
+        scores = buf("scores", (n, bm), torch.float32, 0)
+        new_scores = buf("new_scores", (n, bm), torch.float32)
+        prev, new_tok = buf("prev", (n, bm), torch.int32), buf("new_tok", (n, bm), torch.int32)
+        ys = buf("ys", (Tmax + 1, n, bm), torch.int32, 0)
+        ks = buf("ks", (Tmax, n, bm), torch.int32, 0)
+        done, n_done = buf("done", (n,), torch.int32, 0), buf("n_done", (1,), torch.int32, 0)
+        length = buf("length", (n,), torch.int32, Tmax)
+        cur_len = buf("cur_len", (R,), torch.int32, 1)
+        tok = buf("tok", (R,), torch.int64, Constants.SOS)
+        pos = buf("pos", (R,), torch.int64, 1)
+        row_pad = buf("row_pad", (R,), torch.uint8, 0)
 
         # q | k | v of the self-attention in one projection: weights stacked, all layers in one copy, and kept from
         # call to call while the weights stay what they were (see _prepared)
         nq, nk, nv = H * dk, H * dk, H * dv
-        prep = self._prepared(layers, dt, dev)
         if "qkv_w" not in prep:
             prep["qkv_w"] = torch.cat([self._w(p, dt) for l in layers for p in (l.slf_attn.w_qs.weight, l.slf_attn.w_ks.weight,
                                                                                l.slf_attn.w_vs.weight)], 0).view(NL, nq + nk + nv, d)
@@ -194,10 +231,6 @@ class BeamDecoder:
             y, _, _ = L.add_ln_fwd(o, x, ln.weight.detach(), ln.bias.detach(), row_pad, ln.eps, 0.0, 0)
             return y
 
-        F = layers[0].pos_ffn.w_1.weight.shape[0]
-        # (teams of 8 workgroups x 32 rows, at most 32 teams, all resident together at one workgroup per CU)
-        stack = (use_stack and dt == torch.bfloat16 and (d, H, dk, dv, F) == (512, 8, 64, 64, 2048) and NL <= 8
-                 and R <= 32 * min(32, torch.cuda.get_device_properties(dev).multi_processor_count // 8))
         if stack:
             f32 = lambda p: p.detach().float().contiguous()
 
@@ -215,8 +248,8 @@ class BeamDecoder:
                 prep["fm_w1"] = frag_major([self._w(l.pos_ffn.w_1.weight, dt) for l in layers])
                 prep["fm_w2"] = frag_major([self._w(l.pos_ffn.w_2.weight, dt) for l in layers])
             fm_qkv, fm_sq, fm_w1, fm_w2 = prep["fm_qkv"], prep["fm_sq"], prep["fm_w1"], prep["fm_w2"]
-            rows, keep = [], []
-            for li, l in enumerate(layers):
+            rows = B.get("stack_rows", [])
+            for li, l in enumerate(layers if not rows else []):
                 s_, c_, f_ = l.slf_attn, l.enc_attn, l.pos_ffn
                 row = [fm_qkv[li], qkv_b[li], fm_sq[3 * li], f32(s_.fc.bias), f32(s_.layer_norm.weight),
                        f32(s_.layer_norm.bias), fm_sq[3 * li + 1], f32(c_.w_qs.bias), fm_sq[3 * li + 2],
@@ -224,9 +257,11 @@ class BeamDecoder:
                        f32(f_.w_1.bias), fm_w2[li], f32(f_.w_2.bias), f32(f_.layer_norm.weight),
                        f32(f_.layer_norm.bias), Kc[li], Vc[li], crossK[li], crossV[li]]
                 rows.append(row)
-                keep.append(row)
-            stack_table, _ = L.decode_stack_table(rows)
-            stack_ws = torch.zeros(L.decode_stack_ws_bytes(R), dtype=torch.uint8, device=dev)
+            if "stack_table" not in B:   # (the rows stay referenced with the table of their addresses)
+                B["stack_rows"], B["stack_table"] = rows, L.decode_stack_table(rows)[0]
+            stack_table = B["stack_table"]
+            # (zeroed for every call: a call's first launch has parity 0 whatever the last launch of the call before had)
+            stack_ws = buf("stack_ws", (L.decode_stack_ws_bytes(R),), torch.uint8, 0)
             ln_eps = float(layers[0].slf_attn.layer_norm.eps)
         self.used_stack = bool(stack)
         use_stats = (dt == torch.bfloat16 and d % 8 == 0 and V <= 65536 and os.environ.get("SK_DECODE_TOPK_STATS", "1") != "0")
@@ -235,10 +270,10 @@ class BeamDecoder:
         gen_slab = bool(stack) and use_stats and V <= 1024 * L.generator_chunk_cols() and os.environ.get("SK_DECODE_GEN_SLAB", "1") != "0"
         chunk = L.generator_chunk_cols() if gen_slab else 64
         if stack:
-            stack_out = torch.zeros(((R + 15) // 16 * 16, d), dtype=dt, device=dev)
+            stack_out = buf("stack_out", ((R + 15) // 16 * 16, d), dt, 0, once=True)
         if use_stats:
-            logits_buf = torch.empty((R, V), dtype=torch.float32, device=dev)
-            gen_stats = torch.empty((R, (V + chunk - 1) // chunk, 2), dtype=torch.float32, device=dev)
+            logits_buf = buf("logits", (R, V), torch.float32)
+            gen_stats = buf("gen_stats", (R, (V + chunk - 1) // chunk, 2), torch.float32)
         # (tests that force or trace a step's choices sit between the top-k and the update: they keep the separate launches)
         fused_step = (use_stats and self.forced is None and self.trace is None
                       and os.environ.get("SK_DECODE_FUSED_STEP", "1") != "0")
@@ -313,7 +348,9 @@ class BeamDecoder:
         # and runs of 40 .. 150 steps, four is about where drains and steps past the end cost the same).
         per = 4 if Tmax >= 6 else 2
         if self.use_graph and Tmax >= 3:
-            graph = self._capture_pair(step, cur, dev, per // 2)
+            graph = B.get("graph")   # (captured over this batch shape's kept buffers by an earlier call)
+            if graph is None:
+                graph = B["graph"] = self._capture_pair(step, cur, dev, per // 2)
         mark("first step + graph capture")
         next_look = steps + 4
         while steps < Tmax:
@@ -331,6 +368,8 @@ class BeamDecoder:
                 next_look = steps + 4
         mark("steps")
         del graph
+        if not reuse:
+            B.clear()
         self.last_steps = steps
         if was_training:
             model.train()
@@ -360,7 +399,7 @@ class BeamDecoder:
             k = ks_f[j].take(at) if all_live else np.where((j < T_all)[:, None], ks_f[j].take(at), k)
         toks = toks.transpose(1, 2, 0)                                    # [n][nb][T]: sentences shorter than T_max keep their prefix
         all_hyp = [[toks[s, r, :T_all[s]].tolist() for r in range(nb)] for s in range(n)]
-        all_scores = list(scores_h[:, :n_best].unbind(0))
+        all_scores = list((scores_h.clone() if reuse else scores_h)[:, :n_best].unbind(0))   # (kept buffers are the next call's)
         mark("hypotheses")
         if marks is not None:
             self.times = {b[0]: b[1] - a[1] for a, b in zip(marks, marks[1:])}

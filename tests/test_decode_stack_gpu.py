@@ -358,3 +358,21 @@ def test_slab_generator_search_equals_tiled_generator_search(monkeypatch):
     h0, s0 = BeamDecoder(m, 5, 14, use_graph=True, use_stack=True).run(src, pos, 2)
     assert h1 == h0
     assert max(float((a - b).abs().max()) for a, b in zip(s0, s1)) <= 1e-4
+
+
+def test_kept_buffers_and_graph_serve_later_batches(monkeypatch):
+    """A decoder keeps its buffers and the captured graph per batch shape: three batches of one shape (and one of
+    another in between) through ONE decoder give, batch by batch, exactly what a decoder that builds everything
+    afresh gives, and what an earlier call returned is not touched by a later one."""
+    from specialk_amd.decode import BeamDecoder
+    m = build(2)
+    batches = [batch(24, 9, 9, 1000, s) for s in (11, 12)] + [batch(24, 5, 5, 1000, 13)] + [batch(24, 9, 9, 1000, 14)]
+    kept = BeamDecoder(m, 5, 14, use_graph=True, use_stack=True)
+    got = [kept.run(s, p, 2) for s, p in batches]
+    snap = [[x.clone() for x in g[1]] for g in got]
+    assert len(kept._prep[1]["runs"]) == 2 and all("graph" in b for b in kept._prep[1]["runs"].values())
+    monkeypatch.setenv("SK_DECODE_REUSE", "0")
+    for (s, p), (h, sc), sn in zip(batches, got, snap):
+        h0, s0 = BeamDecoder(m, 5, 14, use_graph=True, use_stack=True).run(s, p, 2)
+        assert h == h0
+        assert all(torch.equal(a, b) and torch.equal(a, c) for a, b, c in zip(sc, s0, sn))
