@@ -51,11 +51,15 @@ def get_subsequent_mask(seq):
 
 
 def _check_ids(seq, pos, n_vocab, n_pos):
-    # nn.Embedding raises on out-of-range ids; the gather kernel would read out of bounds.
-    if seq.numel() and (int(seq.max()) >= n_vocab or int(seq.min()) < 0):
+    # nn.Embedding raises on out-of-range ids; the gather kernel would read out of bounds.  (One host read for the four
+    # extremes.)
+    if not seq.numel():
+        return
+    hi_s, lo_s, hi_p, lo_p = torch.stack((seq.max(), seq.min(), pos.max(), pos.min())).tolist()
+    if hi_s >= n_vocab or lo_s < 0:
         raise IndexError(f"token id out of range [0, {n_vocab})")
-    if pos.numel() and (int(pos.max()) >= n_pos or int(pos.min()) < 0):
-        raise IndexError(f"position {int(pos.max())} outside the position table of {n_pos} rows")
+    if hi_p >= n_pos or lo_p < 0:
+        raise IndexError(f"position {hi_p} outside the position table of {n_pos} rows")
 
 
 class PackPlan:
