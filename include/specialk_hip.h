@@ -470,6 +470,14 @@ int skhip_beam_step(const float* logits, const float* stats, float* new_scores, 
                     uint8_t* pad_hist, const int32_t* hist_in, int32_t* hist_out, int n_sent, int bm, int64_t V,
                     int first_step, int Tc, int max_len, int pad_id, int eos_id, int chunk_cols, void* stream);
 
+/* The hypotheses at the end of a search, for all sentences in one launch: Beam.get_hypothesis
+ * (lib/transformer/Beam.py:103-110) walks the back-pointers of one beam on the host.  ys [steps+1][R] and ks [steps][R]
+ * as skhip_beam_update records them (R = n_sent*bm), length [n_sent].  out[s][r][j] (int32, row stride out_ld >= steps)
+ * = token j of the hypothesis of sentence s that ended as rank r < n_best, for j < min(length[s], steps); the rest of
+ * a row is left as it was.  2 * steps * bm * 4 bytes of LDS per sentence: at most 64 KB (SK_ERR_ARG beyond).        */
+int skhip_beam_backtrack(const int32_t* ys, const int32_t* ks, const int32_t* length, int32_t* out, int n_sent, int bm,
+                         int n_best, int steps, int64_t out_ld, void* stream);
+
 /* Reorder a cache after a beam step: dst[r] = src[src_row[r]] for rows of `row_elems`
  * elements (replaces re-building dec_seq from back-pointers every step, Beam.py:90-110,
  * and the index_select compaction, Translator.py:65-101).                                  */

@@ -26,7 +26,7 @@ EXPORTS = [
     "skhip_decode_stack_ws_bytes", "skhip_decode_stack", "skhip_beam_topk_stats", "skhip_beam_step",
     "skhip_softmax_rows", "skhip_conv_windows", "skhip_cnn_head", "skhip_collate", "skhip_set_reserved_cus",
     "skhip_rowpanel_rows", "skhip_rowpanel_pattern_bytes", "skhip_rowpanel_set_stamps", "skhip_rowpanel_gemm", "skhip_rowpanel_gemm_ln",
-    "skhip_generator_chunk_cols", "skhip_generator_rowstats",
+    "skhip_generator_chunk_cols", "skhip_generator_rowstats", "skhip_beam_backtrack",
 ]
 
 _lib = None
@@ -89,6 +89,7 @@ def load():
     lib.skhip_rowpanel_gemm.argtypes = [c_p, c_i64, c_p, c_p, c_p, c_i64, c_p, c_i64, c_i64, c_int, c_p]
     lib.skhip_rowpanel_gemm_ln.argtypes = [c_p, c_i64, c_p, c_p, c_p, c_i64] + [c_p] * 7 + [c_i64, c_f32, c_f32, c_u64, c_p]
     lib.skhip_generator_rowstats.argtypes = [c_p, c_i64, c_int, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_p]
+    lib.skhip_beam_backtrack.argtypes = [c_p] * 4 + [c_int] * 4 + [c_i64, c_p]
     for name in EXPORTS:
         getattr(lib, name)  # AttributeError here means header and library disagree
     _lib = lib
@@ -621,6 +622,18 @@ def beam_step(logits, stats, out, scores, ys, ks, done, length, n_done, cur_len,
                              _ptr(row_pad), _ptr(pad_hist), _ptr(hist_in), _ptr(hist_out), n_sent, bm, V, int(first_step),
                              Tc, max_len, pad_id, eos_id, int(chunk_cols), _stream())
     _check(rc, "skhip_beam_step")
+
+
+def beam_backtrack(ys, ks, length, n_sent, bm, n_best, steps):
+    """Tokens of the n_best hypotheses of every sentence, int32 [n_sent][n_best][steps] (zeros past a hypothesis'
+    length): the back-pointer walk of Beam.get_hypothesis on the device."""
+    assert ys.dtype == ks.dtype == length.dtype == torch.int32 and ys.is_contiguous() and ks.is_contiguous()
+    assert ys.shape[0] >= steps + 1 and ks.shape[0] >= steps and ys[0].numel() == n_sent * bm == ks[0].numel()
+    out = torch.zeros((n_sent, n_best, max(steps, 1)), dtype=torch.int32, device=ys.device)
+    rc = load().skhip_beam_backtrack(_ptr(ys), _ptr(ks), _ptr(length), _ptr(out), n_sent, bm, n_best, steps, out.shape[2],
+                                     _stream())
+    _check(rc, "skhip_beam_backtrack")
+    return out
 
 
 def decode_stack_ws_bytes(R):

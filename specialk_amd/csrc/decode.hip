@@ -532,6 +532,33 @@ __global__ __launch_bounds__(64) void beam_update_kernel(const float* __restrict
   beam_update_row(new_scores, prev, new_tok, st, blockIdx.x, threadIdx.x);
 }
 
+// Hypotheses of all sentences at the end of a search: Beam.get_hypothesis (lib/transformer/Beam.py:103-110) walks the
+// back-pointers from the last step to the first for one beam; here a workgroup per sentence brings the sentence's
+// columns of ys / ks (the tokens and back-pointers of every step, [step][R]) into LDS and one thread per wanted rank
+// walks them.  out[s][r][j] = token j of the hypothesis that ended as rank r, j < T = min(length[s], steps).
+__global__ __launch_bounds__(64) void beam_backtrack_kernel(const int32_t* __restrict__ ys, const int32_t* __restrict__ ks,
+                                                            const int32_t* __restrict__ length, int32_t* __restrict__ out,
+                                                            int R, int bm, int n_best, int steps, int64_t out_ld) {
+  extern __shared__ int32_t bt[];
+  const int s = blockIdx.x, T = min(length[s], steps);
+  int32_t* y = bt;              // [T][bm]: ys[j + 1]
+  int32_t* k = bt + steps * bm; // [T][bm]: ks[j]
+  for (int i = threadIdx.x; i < T * bm; i += 64) {
+    const int j = i / bm, b = i - j * bm;
+    y[i] = ys[(int64_t)(j + 1) * R + s * bm + b];
+    k[i] = ks[(int64_t)j * R + s * bm + b];
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < n_best) {
+    int32_t* o = out + ((int64_t)s * n_best + threadIdx.x) * out_ld;
+    int b = threadIdx.x;
+    for (int j = T - 1; j >= 0; --j) {
+      o[j] = y[j * bm + b];
+      b = k[j * bm + b];
+    }
+  }
+}
+
 // The three passes of a step in one launch: a workgroup per sentence, a wave per beam row.  The row candidates and
 // the merged beam travel through global memory as in the separate launches (same bytes, same results); what goes
 // is two of the three kernel boundaries of a step, some 10 us each inside a replayed graph.
@@ -708,5 +735,21 @@ extern "C" int skhip_beam_step(const float* logits, const float* stats, float* n
   else BEAM_F(16);
 #undef BEAM_F
   SK_CHECK_LAUNCH("skhip_beam_step");
+  return SK_OK;
+}
+
+extern "C" int skhip_beam_backtrack(const int32_t* ys, const int32_t* ks, const int32_t* length, int32_t* out, int n_sent,
+                                    int bm, int n_best, int steps, int64_t out_ld, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SK_CHECK_ARG(n_sent >= 0 && bm >= 1 && n_best >= 1 && n_best <= bm && n_best <= 64 && steps >= 0 && out_ld >= steps,
+               "skhip_beam_backtrack: bad shape (n_best %d of beam %d, %d steps, row stride %lld)", n_best, bm, steps,
+               (long long)out_ld);
+  const int64_t lds = 2ll * steps * bm * 4;
+  SK_CHECK_ARG(lds <= 64 * 1024, "skhip_beam_backtrack: %d steps x beam %d do not fit 64 KB of LDS", steps, bm);
+  if (n_sent == 0 || steps == 0) return SK_OK;
+  SK_CHECK_ARG(ys && ks && length && out, "skhip_beam_backtrack: null pointer");
+  hipLaunchKernelGGL(beam_backtrack_kernel, dim3((unsigned)n_sent), dim3(64), (size_t)lds, stream, ys, ks, length, out,
+                     n_sent * bm, bm, n_best, steps, out_ld);
+  SK_CHECK_LAUNCH("skhip_beam_backtrack");
   return SK_OK;
 }

@@ -401,23 +401,28 @@ class BeamDecoder:
                 raise _StackGaveUp("skhip_decode_stack: " + ("a team's workgroups ran on more than one XCD" if err == 2 else
                                                              "a team member stopped waiting for its team"))
 
-        # hypotheses: walk the back-pointers on the host (Beam.get_hypothesis, Beam.py:103-110), all sentences and
-        # ranks in step: one gather per position instead of one Python iteration per token
-        ys_h, ks_h = ys[: steps + 1].cpu().numpy(), ks[:steps].cpu().numpy()
-        len_h, scores_h = length.cpu().numpy(), scores
+        # hypotheses: the back-pointer walk of Beam.get_hypothesis (Beam.py:103-110) for all sentences and ranks, on the
+        # device when a sentence's history fits its workgroup's LDS (one launch, one small copy), else on the host
+        # with one gather per position
         nb = min(n_best, bm)
-        T_all = np.minimum(len_h, steps).astype(np.int64)                 # [n]
-        T_max = int(T_all.max()) if n else 0
-        ys_f, ks_f = ys_h.reshape(steps + 1, n * bm), ks_h.reshape(steps, n * bm)
-        base = (np.arange(n, dtype=np.int64) * bm)[:, None]
-        k = np.tile(np.arange(nb, dtype=np.int64)[None, :], (n, 1))       # [n][nb]: beam of rank k0 at the last step
-        toks = np.zeros((max(T_max, 1), n, nb), dtype=np.int64)
-        all_live = bool((T_all == T_max).all())
-        for j in range(T_max - 1, -1, -1):
-            at = base + k
-            toks[j] = ys_f[j + 1].take(at)
-            k = ks_f[j].take(at) if all_live else np.where((j < T_all)[:, None], ks_f[j].take(at), k)
-        toks = toks.transpose(1, 2, 0)                                    # [n][nb][T]: sentences shorter than T_max keep their prefix
+        scores_h = scores
+        if 8 * steps * bm <= 64 * 1024 and os.environ.get("SK_DECODE_BACKTRACK", "1") != "0":
+            toks = L.beam_backtrack(ys, ks, length, n, bm, nb, steps).cpu().numpy()   # [n][nb][steps]
+            T_all = np.minimum(length.cpu().numpy(), steps).astype(np.int64)
+        else:
+            ys_h, ks_h = ys[: steps + 1].cpu().numpy(), ks[:steps].cpu().numpy()
+            T_all = np.minimum(length.cpu().numpy(), steps).astype(np.int64)  # [n]
+            T_max = int(T_all.max()) if n else 0
+            ys_f, ks_f = ys_h.reshape(steps + 1, n * bm), ks_h.reshape(steps, n * bm)
+            base = (np.arange(n, dtype=np.int64) * bm)[:, None]
+            k = np.tile(np.arange(nb, dtype=np.int64)[None, :], (n, 1))   # [n][nb]: beam of rank k0 at the last step
+            toks = np.zeros((max(T_max, 1), n, nb), dtype=np.int64)
+            all_live = bool((T_all == T_max).all())
+            for j in range(T_max - 1, -1, -1):
+                at = base + k
+                toks[j] = ys_f[j + 1].take(at)
+                k = ks_f[j].take(at) if all_live else np.where((j < T_all)[:, None], ks_f[j].take(at), k)
+            toks = toks.transpose(1, 2, 0)                                # [n][nb][T]: sentences shorter than T_max keep their prefix
         all_hyp = [[toks[s, r, :T_all[s]].tolist() for r in range(nb)] for s in range(n)]
         all_scores = list((scores_h.clone() if reuse else scores_h)[:, :n_best].unbind(0))   # (kept buffers are the next call's)
         mark("hypotheses")

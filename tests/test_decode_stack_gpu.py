@@ -376,3 +376,35 @@ def test_kept_buffers_and_graph_serve_later_batches(monkeypatch):
         h0, s0 = BeamDecoder(m, 5, 14, use_graph=True, use_stack=True).run(s, p, 2)
         assert h == h0
         assert all(torch.equal(a, b) and torch.equal(a, c) for a, b, c in zip(sc, s0, sn))
+
+
+def test_device_backtrack_equals_host_walk(monkeypatch):
+    """skhip_beam_backtrack (a workgroup per sentence walks the back-pointers in LDS) against the host walk with one
+    gather per position: same hypotheses for every sentence and rank, with sentences that finish at different steps
+    (a copy of the first source tokens would need a trained model: the random one's searches end when the step
+    limit does, so lengths are forced through `max_token_seq_len` and n_best = 1, 3, 5)."""
+    from specialk_amd.decode import BeamDecoder
+    m = build(1)
+    src, pos = batch(19, 3, 17, 1000, 8)
+    for nb in (1, 3, 5):
+        h1, s1 = BeamDecoder(m, 5, 17, use_graph=True, use_stack=True).run(src, pos, nb)
+        monkeypatch.setenv("SK_DECODE_BACKTRACK", "0")
+        h0, s0 = BeamDecoder(m, 5, 17, use_graph=True, use_stack=True).run(src, pos, nb)
+        monkeypatch.delenv("SK_DECODE_BACKTRACK")
+        assert h1 == h0 and all(len(x) == nb for x in h1)
+    # the kernel alone on a made-up history with unequal lengths
+    from specialk_amd import _lib as L
+    g = torch.Generator().manual_seed(2)
+    n, bm, steps = 7, 4, 23
+    ys = torch.randint(5, 90, (steps + 1, n, bm), generator=g, dtype=torch.int32).to(DEV)
+    ks = torch.randint(0, bm, (steps, n, bm), generator=g, dtype=torch.int32).to(DEV)
+    length = torch.tensor([23, 1, 7, 30, 12, 23, 2], dtype=torch.int32, device=DEV)
+    got = L.beam_backtrack(ys, ks, length, n, bm, 3, steps).cpu()
+    for s in range(n):
+        T = min(int(length[s]), steps)
+        for r in range(3):
+            b, want = r, [0] * steps
+            for j in range(T - 1, -1, -1):
+                want[j] = int(ys[j + 1, s, b])
+                b = int(ks[j, s, b])
+            assert got[s, r].tolist() == want, (s, r)
