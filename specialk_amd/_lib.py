@@ -100,9 +100,14 @@ def version():
     return load().skhip_version().decode()
 
 
+reserved_cus = int(os.environ.get("SKHIP_RESERVE_CUS", "0") or 0)   # what the library currently plans without
+
+
 def set_reserved_cus(n):
     """CUs the large-tile GEMMs leave out of their round planning (held by communication kernels meanwhile)."""
+    global reserved_cus
     _check(load().skhip_set_reserved_cus(int(n)), "skhip_set_reserved_cus")
+    reserved_cus = int(n)
 
 
 def _check(rc, what):

@@ -252,6 +252,7 @@ def _panel_rows_ok(x, T):
     cus = _cu_count.get(x.device)
     if cus is None:
         cus = _cu_count[x.device] = torch.cuda.get_device_properties(x.device).multi_processor_count
+    cus = max(1, cus - L.reserved_cus)   # (CUs held by collectives: a round of 247 panels on 240 CUs is two rounds)
     blocks = -(-T // L.ROWPANEL_ROWS)
     rounds = -(-blocks // cus)
     return blocks >= 0.8 * rounds * cus

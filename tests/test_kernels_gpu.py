@@ -1098,6 +1098,15 @@ def test_reserved_cus_change_scheduling_not_results(L):
         for bad in (-1, 10 ** 6):
             with pytest.raises(RuntimeError):
                 L.set_reserved_cus(bad)
+        # the row-panel kernels take one CU per 104 rows for a whole launch: with CUs held they are only chosen when
+        # their workgroups still fill the rounds they take
+        from specialk_amd import ops
+        cus = torch.cuda.get_device_properties(0).multi_processor_count
+        rows = torch.empty((104 * (cus - 9), 512), dtype=torch.bfloat16, device=DEV)   # a full round less nine CUs
+        L.set_reserved_cus(0)
+        assert ops._panel_rows_ok(rows, rows.shape[0])
+        L.set_reserved_cus(16)
+        assert L.reserved_cus == 16 and not ops._panel_rows_ok(rows, rows.shape[0])
     finally:
         L.set_reserved_cus(0)
 
