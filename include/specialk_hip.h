@@ -428,7 +428,9 @@ int skhip_generator_rowstats(const void* x, int64_t ldx, int x_layout, const voi
  *    Kcache, Vcache bf16 [R][Tc][512], encK, encV bf16 [n_sent][Ls][512]}   (all 16-byte aligned).
  * tok, pos int64 [R]; cur_len int32 [R] (history length of row r including the new position); row_pad uint8 [R];
  * pad_hist uint8 [R][Tc]; hist int32 [R][Tc] (history-row table as for skhip_decode_attn); src_key_pad uint8
- * [n_sent][Ls]; dec_out bf16 [R][512].  R <= 32 x min(32, CUs / 8) rows, sentence of row r = r / bm.
+ * [n_sent][Ls]; dec_out bf16 [R][512] (out_layout SK_ROWS_PLAIN) or, with SK_ROWS_FRAGMENT_MAJOR, the same rows in the
+ * order skhip_generator_rowstats reads them in (see there), in a buffer of ceil(R / 16) * 16 rows of which only rows
+ * < R are written.  R <= 32 x min(32, CUs / 8) rows, sentence of row r = r / bm.
  * workspace: skhip_decode_stack_ws_bytes(R) bytes, 256-byte aligned, which the caller zeroes ONCE before the first
  * call of a decode run (the team barriers' words: the first 1024 bytes and the last 4096); parity: 0 / 1, alternating
  * from call to call (the launch of one parity resets the barrier words and XCC masks of the other).  The first 1024 bytes hold, as int32 words: [0, 64) team
