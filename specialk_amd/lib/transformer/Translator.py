@@ -41,5 +41,10 @@ class Translator(object):
         batch_hyp[i][j] is the j-th best token list of sentence i (without SOS) and
         batch_scores[i] the matching n_best summed log-probabilities."""
         src_seq, src_pos = src_seq.to(self.device), src_pos.to(self.device)
-        decoder = BeamDecoder(self.model, self.opt.beam_size, self.max_token_seq_len)
-        return decoder.run(src_seq, src_pos, self.opt.n_best)
+        # one decoder for as long as the model, the beam size and the length limit stay what they are (all three are
+        # assignable): it keeps the prepared weights, and per batch shape its buffers and captured graph, between calls
+        key = (self.model, self.opt.beam_size, self.max_token_seq_len)
+        held = getattr(self, "_decoder", None)
+        if held is None or held[0][0] is not key[0] or held[0][1:] != key[1:]:
+            held = self._decoder = (key, BeamDecoder(*key))
+        return held[1].run(src_seq, src_pos, self.opt.n_best)
